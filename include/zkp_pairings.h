@@ -1,0 +1,132 @@
+/*
+ * include/zkp_pairings.h -- C ABI of libzkp_pairings.so, the MI355X (gfx950) batched BLS12-381
+ * pairing engine.  This is the drop-in boundary for the pairing-check path of
+ * 0xWOLAND/zkvm-pairings: a Rust/cgo/ctypes binding declares exactly these symbols
+ * (see INTEGRATION.md for the Rust `extern "C"` block).
+ *
+ * Reference interface each entry point stands in for (paths relative to /root/reference):
+ *   zkp_pairing_batch               pairing(&G1Affine,&G2Affine)->Gt        src/pairings.rs (declared at
+ *   zkp_multi_miller_loop_batch     multi_miller_loop(&[(G1,G2)])            src/lib.rs:12; the file is EMPTY in
+ *   zkp_final_exponentiation_batch  MillerLoopResult::final_exponentiation   this snapshot - semantics defined in
+ *   zkp_pairing_check_batch         pairing(..) == Gt::identity()            SURVEY.md S6 / DESIGN.md)
+ *   zkp_gt_identity                 Gt::identity() == Fp12::one()            src/fp12.rs:87-89
+ *   zkp_g1_is_valid_batch           G1Affine::is_valid                       src/g1.rs:49-62  (is_on_curve :95-101,
+ *                                                                            is_torsion_free :111-115)
+ *   zkp_g2_is_valid_batch           G2Affine::is_valid                       src/g2.rs:57-69  (:109-120, :166-170)
+ *   zkp_g1_mul_batch / g2           &G1Affine * &Fr / &G2Affine * &Fr         src/g1.rs:130-153 (bit-0 bug F5 NOT
+ *                                                                            mirrored), src/g2.rs:185-208
+ *   zkp_fp_op_batch                 bls12381_sys_bigint(out, op, a, b)       src/fp.rs:376,443 (op 0 = mul, 1 = add)
+ *
+ * Wire formats (all little-endian, canonical representatives in [0,p), identical to the
+ * reference's in-memory structs):
+ *   fp    uint64_t[6]                          Fp.0                         src/fp.rs:24
+ *   fp2   c0 | c1                    (12 u64)  Fp2{c0,c1}                   src/fp2.rs:10-15
+ *   fp12  c0.c0.c0, c0.c0.c1, c0.c1.c0 ... c1.c2.c1 (72 u64)                src/fp12.rs:13-16, src/fp6.rs:13-17
+ *   g1    x | y                      (12 u64)  + parallel uint8 is_infinity src/g1.rs:7-11
+ *   g2    x.c0 | x.c1 | y.c0 | y.c1  (24 u64)  + parallel uint8 is_infinity src/g2.rs:8-12
+ *   fr    uint64_t[4] canonical scalar                                      src/fr.rs (Fr.0)
+ *
+ * Ownership: the caller owns every buffer it passes (host or device); the library owns the
+ * workspace inside zkp_ctx.  Errors: 0 on success, negative zkp_status otherwise; the library never
+ * aborts and never unwinds across this boundary (the reference's panics F7 become status bytes).
+ * Inputs must be canonical (< p): non-canonical limbs give ZKP_ERR_NONCANONICAL when validation is on
+ * (zkp_set_validate), unspecified field values otherwise.
+ * Threading: a zkp_ctx is bound to one GPU and is not thread-safe; use one ctx per thread / rank.
+ * There is NO CPU fallback: zkp_init fails with ZKP_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef ZKP_PAIRINGS_H
+#define ZKP_PAIRINGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zkp_ctx zkp_ctx;
+
+typedef enum {
+    ZKP_OK = 0,
+    ZKP_ERR_ARG = -1,          /* null pointer / bad size */
+    ZKP_ERR_NO_DEVICE = -2,    /* no usable HIP device */
+    ZKP_ERR_HIP = -3,          /* a HIP runtime call failed; see zkp_last_error */
+    ZKP_ERR_NONCANONICAL = -4, /* an input limb array is >= p (validation mode) */
+    ZKP_ERR_OOM = -5
+} zkp_status;
+
+/* which Miller-loop/final-exp kernel family the context uses */
+typedef enum {
+    ZKP_KERNEL_AUTO = 0,
+    ZKP_KERNEL_THREAD = 1,  /* one pairing per lane, 12x32-bit Montgomery limbs */
+    ZKP_KERNEL_COOP = 2     /* lane-group-cooperative, LDS-staged tower (hot path) */
+} zkp_kernel_kind;
+
+int zkp_abi_version(void);
+const char* zkp_strerror(int status);
+
+/* device = HIP device ordinal of this process (LOCAL_RANK under torchrun). */
+int zkp_init(int device, zkp_ctx** out_ctx);
+void zkp_free(zkp_ctx* ctx);
+const char* zkp_last_error(const zkp_ctx* ctx);
+int zkp_set_validate(zkp_ctx* ctx, int on);
+int zkp_set_kernel(zkp_ctx* ctx, int kind /* zkp_kernel_kind */);
+int zkp_device_info(const zkp_ctx* ctx, int* cus, int* clock_khz, char* name, size_t name_len);
+
+/* Gt::identity(): 72 u64, c0.c0.c0 = 1, rest 0. */
+const uint64_t* zkp_gt_identity(void);
+
+/* ---- host-pointer entry points (H2D copy, kernels, D2H copy, synchronous) ---------------------- */
+/* out_gt[i] = pairing(g1[i], g2[i]); inf1/inf2 may be NULL (= no infinities). */
+int zkp_pairing_batch(zkp_ctx* ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
+                      size_t n, uint64_t* out_gt);
+/* n_checks groups of k consecutive pairs; out_ml[c] = multi_miller_loop(group c) (72 u64 each). */
+int zkp_multi_miller_loop_batch(zkp_ctx* ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1,
+                                const uint8_t* inf2, size_t n_checks, size_t k, uint64_t* out_ml);
+int zkp_final_exponentiation_batch(zkp_ctx* ctx, const uint64_t* f, size_t n, uint64_t* out_gt);
+/* ok[c] = (final_exponentiation(multi_miller_loop(group c)) == Gt::identity()); ok may be NULL.
+ * *all_ok = AND over this call's checks (the cross-GPU AND is the caller's single RCCL all-reduce). */
+int zkp_pairing_check_batch(zkp_ctx* ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1,
+                            const uint8_t* inf2, size_t n_checks, size_t k, uint8_t* ok, int* all_ok);
+/* status[i]: 0 valid (or infinity), 1 not on curve, 2 not torsion free. */
+int zkp_g1_is_valid_batch(zkp_ctx* ctx, const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* status);
+int zkp_g2_is_valid_batch(zkp_ctx* ctx, const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status);
+/* out[i] = [k_i] p_i (affine); base_stride 0 broadcasts one base point. out_inf may be NULL. */
+int zkp_g1_mul_batch(zkp_ctx* ctx, const uint64_t* base, size_t base_stride, const uint64_t* scalars, size_t n,
+                     uint64_t* out, uint8_t* out_inf);
+int zkp_g2_mul_batch(zkp_ctx* ctx, const uint64_t* base, size_t base_stride, const uint64_t* scalars, size_t n,
+                     uint64_t* out, uint8_t* out_inf);
+/* batched field op in the zkVM precompile shape: op 0 = mul, 1 = add (src/fp.rs:376,443) */
+int zkp_fp_op_batch(zkp_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+
+/* ---- device-pointer entry points (buffers already resident in HBM; asynchronous on `stream`) ---- */
+/* `stream` is a hipStream_t passed as void* (NULL = default stream).  Same formats as above. */
+int zkp_pairing_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1, const void* d_inf2,
+                          size_t n, void* d_out_gt, void* stream);
+int zkp_multi_miller_loop_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1,
+                                    const void* d_inf2, size_t n_checks, size_t k, void* d_out_ml, void* stream);
+int zkp_final_exponentiation_batch_dev(zkp_ctx* ctx, const void* d_f, size_t n, void* d_out_gt, void* stream);
+/* d_ok: n_checks bytes (may be NULL); d_all_ok: one int32 written with the AND (may be NULL). */
+int zkp_pairing_check_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1,
+                                const void* d_inf2, size_t n_checks, size_t k, void* d_ok, void* d_all_ok,
+                                void* stream);
+/* pairing() and the Gt::identity() check in one pass: Gt out (may be NULL) + ok bytes + AND flag. */
+int zkp_pairing_gt_check_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1,
+                                   const void* d_inf2, size_t n_checks, size_t k, void* d_out_gt, void* d_ok,
+                                   void* d_all_ok, void* stream);
+int zkp_g1_is_valid_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_inf, size_t n, void* d_status, void* stream);
+int zkp_g2_is_valid_batch_dev(zkp_ctx* ctx, const void* d_g2, const void* d_inf, size_t n, void* d_status, void* stream);
+int zkp_g1_mul_batch_dev(zkp_ctx* ctx, const void* d_base, size_t base_stride, const void* d_scalars, size_t n,
+                         void* d_out, void* d_out_inf, void* stream);
+int zkp_g2_mul_batch_dev(zkp_ctx* ctx, const void* d_base, size_t base_stride, const void* d_scalars, size_t n,
+                         void* d_out, void* d_out_inf, void* stream);
+
+/* ---- measurement helper used by bench.py: times `reps` launches of the fused pairing kernel on
+ * ctx's own stream with HIP events recorded on THAT stream; returns average ms per launch. ---- */
+int zkp_time_pairing_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out_gt, int reps,
+                         float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,282 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(zkvm_pairings_amd.PairingEngine -> libzkp_pairings.so), against the CPU oracle on the same seeded
+inputs, the committed golden vectors, and size-independent properties at larger sizes.
+Bar: bit-exact (integer arithmetic mod p; canonical limbs)."""
+import numpy as np
+import pytest
+
+import bls12_381_model as m
+import oracle_lib as o
+
+pytestmark = pytest.mark.gpu
+
+H = lambda s: int(s, 16)
+NTHREADS = 16
+
+
+def A(hexes):
+    return o.ints_to_arr([H(h) for h in hexes])
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from zkvm_pairings_amd import PairingEngine
+    e = PairingEngine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module", params=["thread", "coop"])
+def keng(request, eng):
+    """the same engine with each Miller/final-exp kernel family selected"""
+    from zkvm_pairings_amd import _lib
+    try:
+        eng.set_kernel(request.param)
+    except _lib.ZkpError:
+        pytest.skip("kernel family %s not available in this build" % request.param)
+    yield eng
+    eng.set_kernel("auto")
+
+
+def rnd_fp_arr(seed, n):
+    g = m.SplitMix64(seed)
+    return np.stack([o.to_limbs(g.below(m.P)) for _ in range(n)])
+
+
+def test_fp_op_precompile_shape(eng):
+    n = 4096
+    a, b = rnd_fp_arr(11, n), rnd_fp_arr(12, n)
+    edge = np.stack([o.to_limbs(v) for v in (0, 1, m.P - 1, m.P - 2, 2, (m.P + 1) // 2)])
+    a[: len(edge)] = edge
+    b[: len(edge)] = edge[::-1]
+    mul, add = eng.fp_op(0, a, b), eng.fp_op(1, a, b)
+    for i in list(range(16)) + list(range(0, n, 97)):
+        assert np.array_equal(mul[i], o.fp_mul(a[i], b[i]))
+        assert np.array_equal(add[i], o.fp_add(a[i], b[i]))
+    # full-batch check with python ints (independent of the oracle too)
+    ai, bi = o.arr_to_ints(a), o.arr_to_ints(b)
+    assert o.arr_to_ints(mul) == [x * y % m.P for x, y in zip(ai, bi)]
+    assert o.arr_to_ints(add) == [(x + y) % m.P for x, y in zip(ai, bi)]
+    assert eng.fp_op(0, a[:0], b[:0]).shape == (0, 6)
+
+
+def test_scalar_mul_golden_and_oracle(eng, model_vectors):
+    from zkvm_pairings_amd import synthetic
+    g = model_vectors["groups"]
+    ks = [H(v["k"]) for v in g["g1_mul"]]
+    sc = np.stack([synthetic.int_to_scalar(k) for k in ks])
+    p1, i1 = eng.g1_mul(synthetic.G1_GENERATOR, sc)
+    p2, i2 = eng.g2_mul(synthetic.G2_GENERATOR, sc)
+    assert not i1.any() and not i2.any()
+    for j in range(len(ks)):
+        assert o.arr_to_ints(p1[j]) == [H(x) for x in g["g1_mul"][j]["p"]]
+        assert o.arr_to_ints(p2[j]) == [H(x) for x in g["g2_mul"][j]["p"]]
+    # [r]G = infinity, [0]G = infinity
+    sc = np.stack([synthetic.int_to_scalar(m.R_ORDER), synthetic.int_to_scalar(0)])
+    assert eng.g1_mul(synthetic.G1_GENERATOR, sc)[1].tolist() == [1, 1]
+    assert eng.g2_mul(synthetic.G2_GENERATOR, sc)[1].tolist() == [1, 1]
+    # per-element bases, random scalars vs the oracle
+    s = synthetic.scalars(99, 24)
+    b1, _ = eng.g1_mul(synthetic.G1_GENERATOR, synthetic.scalars(98, 24))
+    b2, _ = eng.g2_mul(synthetic.G2_GENERATOR, synthetic.scalars(97, 24))
+    r1, _ = eng.g1_mul(b1, s)
+    r2, _ = eng.g2_mul(b2, s)
+    assert np.array_equal(r1, o.g1_mul_batch(b1, s, NTHREADS))
+    assert np.array_equal(r2, o.g2_mul_batch(b2, s, NTHREADS))
+
+
+def test_validity_golden_and_oracle(eng, model_vectors, ref_kats):
+    from zkvm_pairings_amd import synthetic
+    g = model_vectors["groups"]
+    pts = np.stack([A(v["p"]) for v in g["g1_validity"]] + [synthetic.G1_GENERATOR, A(ref_kats["g1_double"]["b"])])
+    want = [v["status"] for v in g["g1_validity"]] + [0, 0]
+    assert eng.g1_is_valid(pts).tolist() == want
+    assert eng.g1_is_valid(pts).tolist() == [o.g1_is_valid(p) for p in pts]
+    pts2 = np.stack([A(v["p"]) for v in g["g2_validity"]] + [synthetic.G2_GENERATOR, A(ref_kats["g2_gen_double"]), A(ref_kats["g2_not_torsion_free"])])
+    want2 = [v["status"] for v in g["g2_validity"]] + [0, 0, o.g2_is_valid(A(ref_kats["g2_not_torsion_free"]))]
+    assert eng.g2_is_valid(pts2).tolist() == want2
+    # infinity flag => valid regardless of coordinates (reference src/g1.rs:50-52)
+    inf = np.ones(len(pts), dtype=np.uint8)
+    assert not eng.g1_is_valid(pts, inf).any()
+    # a batch of honest subgroup points
+    p1, _ = eng.g1_mul(synthetic.G1_GENERATOR, synthetic.scalars(5, 130))
+    p2, _ = eng.g2_mul(synthetic.G2_GENERATOR, synthetic.scalars(6, 130))
+    assert not eng.g1_is_valid(p1).any() and not eng.g2_is_valid(p2).any()
+    assert eng.g1_is_valid(pts[:0]).shape == (0,)
+
+
+def test_pairing_golden(keng, model_vectors):
+    from zkvm_pairings_amd import synthetic
+    pr = model_vectors["pairing"]
+    ml = keng.multi_miller_loop(synthetic.G1_GENERATOR, synthetic.G2_GENERATOR, 1)
+    assert o.arr_to_ints(ml[0]) == [H(x) for x in pr["gen"]["miller"]]
+    gt = keng.pairing(synthetic.G1_GENERATOR, synthetic.G2_GENERATOR)
+    assert o.arr_to_ints(gt[0]) == [H(x) for x in pr["gen"]["gt"]]
+    assert np.array_equal(keng.final_exponentiation(ml), gt)
+    g1 = np.stack([A(c["g1"]) for c in pr["random"]])
+    g2 = np.stack([A(c["g2"]) for c in pr["random"]])
+    ml = keng.multi_miller_loop(g1, g2, 1)
+    gt = keng.pairing(g1, g2)
+    for j, c in enumerate(pr["random"]):
+        assert o.arr_to_ints(ml[j]) == [H(x) for x in c["miller"]]
+        assert o.arr_to_ints(gt[j]) == [H(x) for x in c["gt"]]
+    for name, expect in (("multi3", True), ("multi3_bad", False)):
+        c = pr[name]
+        g1 = np.stack([A(x) for x in c["g1"]])
+        g2 = np.stack([A(x) for x in c["g2"]])
+        ml = keng.multi_miller_loop(g1, g2, 3)
+        assert o.arr_to_ints(ml[0]) == [H(x) for x in c["miller"]]
+        assert o.arr_to_ints(keng.final_exponentiation(ml)[0]) == [H(x) for x in c["gt"]]
+        ok, allok = keng.pairing_check(g1, g2, 3)
+        assert bool(ok[0]) == expect and allok == expect
+
+
+def test_pairing_batch_vs_oracle(keng):
+    from zkvm_pairings_amd import synthetic
+    n = 192  # ragged: not a multiple of the wave or block size
+    g1, g2, _, _ = synthetic.random_pairs(keng, n, seed=1234)
+    # infinities sprinkled on either side
+    inf1 = np.zeros(n, dtype=np.uint8)
+    inf2 = np.zeros(n, dtype=np.uint8)
+    inf1[[3, 64, 100]] = 1
+    inf2[[5, 64, 191]] = 1
+    want = o.pairing_batch(g1, g2, inf1, inf2, NTHREADS)
+    got = keng.pairing(g1, g2, inf1, inf2)
+    assert np.array_equal(got, want)
+    one = keng.gt_identity()
+    for j in (3, 5, 64, 100, 191):
+        assert np.array_equal(got[j], one)
+    ml = keng.multi_miller_loop(g1, g2, 1, inf1, inf2)
+    assert np.array_equal(ml[:32], o.multi_miller_loop_batch(g1[:32], g2[:32], 32, 1, inf1[:32], inf2[:32]))
+    assert np.array_equal(keng.final_exponentiation(ml), want)
+    assert keng.pairing(g1[:0], g2[:0]).shape == (0, 72)
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 9])
+def test_multi_miller_vs_oracle(keng, k):
+    from zkvm_pairings_amd import synthetic
+    n_checks = 20
+    g1, g2, _, _ = synthetic.random_pairs(keng, n_checks * k, seed=77 + k)
+    inf1 = np.zeros(n_checks * k, dtype=np.uint8)
+    inf1[1] = 1
+    got = keng.multi_miller_loop(g1, g2, k, inf1, None)
+    want = o.multi_miller_loop_batch(g1, g2, n_checks, k, inf1, None)
+    assert np.array_equal(got, want)
+
+
+def _groth_like_checks(eng, n_checks, seed, bad_every):
+    """3-pair checks with a1 b1 + a2 b2 + a3 b3 = 0 (mod r); every bad_every-th check is perturbed."""
+    from zkvm_pairings_amd import synthetic
+    r = m.R_ORDER
+    a = synthetic.scalars(seed, 3 * n_checks).reshape(n_checks, 3, 4)
+    b = synthetic.scalars(seed + 1, 3 * n_checks).reshape(n_checks, 3, 4)
+    expect = np.ones(n_checks, dtype=np.uint8)
+    for c in range(n_checks):
+        ai = [synthetic.scalar_to_int(x) for x in a[c]]
+        bi = [synthetic.scalar_to_int(x) for x in b[c]]
+        a3 = (-(ai[0] * bi[0] + ai[1] * bi[1]) * pow(bi[2], -1, r)) % r
+        if bad_every and c % bad_every == 0:
+            a3 = (a3 + 1) % r
+            expect[c] = 0
+        a[c, 2] = synthetic.int_to_scalar(a3)
+    g1, i1 = eng.g1_mul(synthetic.G1_GENERATOR, a.reshape(-1, 4))
+    g2, i2 = eng.g2_mul(synthetic.G2_GENERATOR, b.reshape(-1, 4))
+    return g1, g2, expect
+
+
+def test_pairing_check_groth16_shape(keng):
+    g1, g2, expect = _groth_like_checks(keng, 96, 4242, 7)
+    ok, allok = keng.pairing_check(g1, g2, 3)
+    assert np.array_equal(ok, expect) and not allok
+    assert np.array_equal(ok[:16], o.pairing_check_batch(g1[:48], g2[:48], 16, 3))
+    g1, g2, expect = _groth_like_checks(keng, 64, 4343, 0)
+    ok, allok = keng.pairing_check(g1, g2, 3)
+    assert ok.all() and allok
+
+
+def test_properties_at_size(keng):
+    """size-independent properties on a batch the CPU oracle would take minutes for:
+    e(P,Q) * e(-P,Q) == 1 through one shared final exponentiation, for every element."""
+    from zkvm_pairings_amd import synthetic
+    n = 4096
+    g1, g2, _, _ = synthetic.random_pairs(keng, n, seed=31337)
+    neg = g1.copy()
+    # -y = p - y on canonical limbs (python ints; host side of the test, not the product)
+    for j in range(n):
+        neg[j, 6:] = o.to_limbs((m.P - o.from_limbs(g1[j, 6:])) % m.P)
+    G1 = np.stack([g1, neg], axis=1).reshape(2 * n, 12)
+    G2 = np.stack([g2, g2], axis=1).reshape(2 * n, 24)
+    ok, allok = keng.pairing_check(G1, G2, 2)
+    assert ok.all() and allok
+    # and the plain pairings are NOT one, and a 64-element sample matches the oracle bit for bit
+    ok1, all1 = keng.pairing_check(g1, g2, 1)
+    assert not ok1.any() and not all1
+    sel = np.arange(0, n, n // 64)
+    assert np.array_equal(keng.pairing(g1[sel], g2[sel]), o.pairing_batch(g1[sel], g2[sel], nthreads=NTHREADS))
+
+
+def test_bilinearity_on_gpu(keng):
+    from zkvm_pairings_amd import synthetic
+    a, b = 0x1234567, 0x89ABCDE
+    p1, _ = keng.g1_mul(synthetic.G1_GENERATOR, synthetic.int_to_scalar(a))
+    q1, _ = keng.g2_mul(synthetic.G2_GENERATOR, synthetic.int_to_scalar(b))
+    pab, _ = keng.g1_mul(synthetic.G1_GENERATOR, synthetic.int_to_scalar(a * b))
+    lhs = keng.pairing(p1, q1)
+    rhs = keng.pairing(pab, synthetic.G2_GENERATOR)
+    assert np.array_equal(lhs, rhs)
+    assert np.array_equal(lhs[0], o.fp12_pow_u64(o.pairing_batch(o.g1_generator(), o.g2_generator())[0], a * b))
+
+
+def test_device_tensor_api_matches_host_api(keng):
+    import torch
+    from zkvm_pairings_amd import synthetic
+    n = 70
+    g1, g2, _, _ = synthetic.random_pairs(keng, n, seed=555)
+    t1, t2, _, _ = synthetic.random_pairs(keng, n, seed=555, device_tensors=True)
+    assert np.array_equal(t1.cpu().numpy().view(np.uint64), g1) and np.array_equal(t2.cpu().numpy().view(np.uint64), g2)
+    gt = keng.pairing(t1, t2)
+    torch.cuda.synchronize()
+    assert np.array_equal(gt.cpu().numpy().view(np.uint64), keng.pairing(g1, g2))
+    ml = keng.multi_miller_loop(t1, t2, 1)
+    fe = keng.final_exponentiation(ml)
+    ok, allok = keng.pairing_check(t1, t2, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(fe, gt) and not ok.any().item() and allok.item() == 0
+    st1, st2 = keng.g1_is_valid(t1), keng.g2_is_valid(t2)
+    torch.cuda.synchronize()
+    assert not st1.any().item() and not st2.any().item()
+    out = torch.empty((n, 72), dtype=torch.int64, device=t1.device)
+    okb = torch.empty(n, dtype=torch.uint8, device=t1.device)
+    flag = torch.empty(1, dtype=torch.int32, device=t1.device)
+    keng.pairing_gt_check(t1, t2, 1, out, okb, flag)
+    torch.cuda.synchronize()
+    assert torch.equal(out, gt) and flag.item() == 0
+
+
+def test_validation_mode_rejects_noncanonical(eng):
+    from zkvm_pairings_amd import _lib, synthetic
+    bad = synthetic.G1_GENERATOR.copy()
+    bad[:6] = o.to_limbs(m.P)  # x = p is not canonical
+    eng.set_validate(True)
+    try:
+        with pytest.raises(_lib.ZkpError) as ei:
+            eng.pairing(bad, synthetic.G2_GENERATOR)
+        assert ei.value.status == -4
+        assert eng.pairing(synthetic.G1_GENERATOR, synthetic.G2_GENERATOR).shape == (1, 72)
+    finally:
+        eng.set_validate(False)
+
+
+def test_reference_api_mirror():
+    """pairing()/multi_miller_loop()/final_exponentiation()/Gt::identity() object API."""
+    import zkvm_pairings_amd as z
+    P, Q = z.G1Affine.generator(), z.G2Affine.generator()
+    assert P.is_valid() is None and Q.is_valid() is None
+    e = z.pairing(P, Q)
+    assert not e.is_identity()
+    assert z.multi_miller_loop([(P, Q)]).final_exponentiation() == e
+    assert z.pairing(z.G1Affine.identity(), Q) == z.Gt.identity()
+    assert z.pairing(P * 6, Q) == z.pairing(P * 2, Q * 3)
+    assert z.G1Affine(P.x, (P.y + 1) % m.P).is_valid() == "Point is not on curve"
+    negP = z.G1Affine(P.x, m.P - P.y)
+    assert z.multi_miller_loop([(P, Q), (negP, Q)]).final_exponentiation() == z.Gt.identity()

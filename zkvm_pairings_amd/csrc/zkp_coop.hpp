@@ -1,0 +1,28 @@
+// zkp_coop.hpp -- interface between the C-ABI dispatcher (zkp_pairings.hip) and the
+// lane-cooperative kernel family (zkp_coop.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace zkp {
+
+struct CoopState {
+    bool available = false;
+    int cus = 0;
+    void* d_prog = nullptr;   // microcode tables resident in HBM
+    void* d_ws = nullptr;     // per-launch workspace (Miller outputs between the two phases)
+    size_t ws_bytes = 0;
+};
+
+hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop);
+void coop_free(CoopState* st);
+// true when `kind` (zkp_kernel_kind) routes the pairing path through the cooperative kernels
+bool coop_selected(const CoopState* st, int kind);
+hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks,
+                       size_t k, uint64_t* out, hipStream_t s);
+hipError_t coop_final_exp(CoopState* st, const uint64_t* f, size_t n, uint64_t* out, hipStream_t s);
+hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks,
+                        size_t k, uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s);
+
+}  // namespace zkp

@@ -1,0 +1,633 @@
+// zkp_pairings.hip -- libzkp_pairings.so: C ABI (include/zkp_pairings.h) + the one-element-per-lane
+// kernel family for gfx950.  The lane-cooperative hot-path kernels live in zkp_coop.hip and are
+// dispatched from here when the context's kernel kind selects them.
+//
+// There is no CPU fallback anywhere in this file: every entry point either runs HIP kernels or
+// returns a negative status.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/zkp_pairings.h"
+#include "zkp_field.hpp"
+#include "zkp_coop.hpp"
+
+using namespace zkp;
+
+// =============================================================================== kernels (thread family)
+namespace {
+
+constexpr int TPB = 64;   // threads per block for the scratch-heavy tower kernels
+constexpr int KMAX = 4;   // pairs per shared-squaring Miller loop; larger k is split and multiplied
+
+__device__ inline bool pair_live(const uint8_t* inf1, const uint8_t* inf2, size_t i) {
+    return !((inf1 && inf1[i]) || (inf2 && inf2[i]));
+}
+
+// Miller loop over pairs [base, base+k) (k <= KMAX) with shared squarings; result NOT conjugated.
+__device__ __attribute__((noinline)) void miller_group(Fp12* f, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1,
+                                                        const uint8_t* inf2, size_t base, int k) {
+    G1A ps[KMAX];
+    G2A qs[KMAX];
+    G2P rs[KMAX];
+    bool live[KMAX];
+    for (int j = 0; j < k; j++) {
+        live[j] = pair_live(inf1, inf2, base + j);
+        fp_load(&ps[j].x, g1 + 12 * (base + j));
+        fp_load(&ps[j].y, g1 + 12 * (base + j) + 6);
+        fp2_load(&qs[j].x, g2 + 24 * (base + j));
+        fp2_load(&qs[j].y, g2 + 24 * (base + j) + 12);
+        rs[j].x = qs[j].x;
+        rs[j].y = qs[j].y;
+        fp2_one(&rs[j].z);
+    }
+    fp12_one(f);
+    Line l;
+    bool found_one = false;
+    for (int b = 63; b >= 0; b--) {
+        bool bit = ((ZKP_BLS_X >> 1) >> b) & 1;
+        if (!found_one) { found_one = bit; continue; }
+        for (int j = 0; j < k; j++)
+            if (live[j]) { doubling_step(&l, &rs[j]); ell(f, &l, &ps[j]); }
+        if (bit)
+            for (int j = 0; j < k; j++)
+                if (live[j]) { addition_step(&l, &rs[j], &qs[j]); ell(f, &l, &ps[j]); }
+        fp12_sqr(f, f);
+    }
+    for (int j = 0; j < k; j++)
+        if (live[j]) { doubling_step(&l, &rs[j]); ell(f, &l, &ps[j]); }
+}
+
+// multi_miller_loop of one check of k pairs (any k): product of <=KMAX-pair groups, then conjugate
+__device__ __attribute__((noinline)) void miller_check(Fp12* f, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1,
+                                                        const uint8_t* inf2, size_t base, size_t k) {
+    fp12_one(f);
+    bool first = true;
+    for (size_t off = 0; off < k; off += KMAX) {
+        int kk = (int)((k - off) < (size_t)KMAX ? (k - off) : (size_t)KMAX);
+        if (first) { miller_group(f, g1, g2, inf1, inf2, base + off, kk); first = false; }
+        else { Fp12 g; miller_group(&g, g1, g2, inf1, inf2, base + off, kk); fp12_mul(f, f, &g); }
+    }
+    fp12_conj(f, f);  // x < 0
+}
+
+__global__ void __launch_bounds__(TPB) k_miller(const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
+                                                 size_t n_checks, size_t k, uint64_t* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n_checks) return;
+    Fp12 f;
+    miller_check(&f, g1, g2, inf1, inf2, i * k, k);
+    fp12_store(out + 72 * i, &f);
+}
+
+__global__ void __launch_bounds__(TPB) k_final_exp(const uint64_t* in, size_t n, uint64_t* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fp12 f, r;
+    fp12_load(&f, in + 72 * i);
+    final_exponentiation(&r, &f);
+    fp12_store(out + 72 * i, &r);
+}
+
+// fused: out[i] = final_exp(multi_miller_loop(check i)); optional ok byte + AND flag
+__global__ void __launch_bounds__(TPB) k_pairing(const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
+                                                  size_t n_checks, size_t k, uint64_t* out_gt, uint8_t* ok, int* all_ok) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n_checks) return;
+    Fp12 f, r;
+    miller_check(&f, g1, g2, inf1, inf2, i * k, k);
+    final_exponentiation(&r, &f);
+    if (out_gt) fp12_store(out_gt + 72 * i, &r);
+    if (ok || all_ok) {
+        Fp12 one;
+        fp12_one(&one);
+        bool is_one = fp12_eq(&r, &one);
+        if (ok) ok[i] = is_one ? 1 : 0;
+        if (all_ok && !is_one) atomicAnd(all_ok, 0);
+    }
+}
+
+__global__ void k_set_int(int* p, int v) { *p = v; }
+
+// reference src/g1.rs:49-62: 0 ok / 1 not on curve / 2 not torsion free
+__global__ void __launch_bounds__(TPB) k_g1_valid(const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* status) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    if (inf && inf[i]) { status[i] = 0; return; }
+    Fp x, y, t, u, b;
+    fp_load(&x, g1 + 12 * i);
+    fp_load(&y, g1 + 12 * i + 6);
+    fp_sqr(&t, &y);
+    fp_sqr(&u, &x);
+    fp_mul(&u, &u, &x);
+    fp_set(&b, K_M_B);
+    fp_add(&u, &u, &b);
+    if (!fp_eq(&t, &u)) { status[i] = 1; return; }
+    // -[X][X]P == (beta x, y)  <=>  [X][X]P == (beta x, -y)
+    uint64_t kx = ZKP_BLS_X;
+    Jac<FpOps> q;
+    jac_mul<FpOps>(&q, &x, &y, &kx, 1);
+    Fp ax, ay;
+    bool fin = jac_to_affine<FpOps>(&ax, &ay, &q);
+    bool ok = false;
+    if (fin) {
+        jac_mul<FpOps>(&q, &ax, &ay, &kx, 1);
+        Fp bx, ny, beta;
+        fp_set(&beta, K_M_BETA);
+        fp_mul(&bx, &x, &beta);
+        fp_neg(&ny, &y);
+        ok = jac_eq_affine<FpOps>(&q, &bx, &ny);
+    }
+    status[i] = ok ? 0 : 2;
+}
+
+// reference src/g2.rs:57-69: psi(P) == -[X]P
+__global__ void __launch_bounds__(TPB) k_g2_valid(const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    if (inf && inf[i]) { status[i] = 0; return; }
+    Fp2 x, y, t, u, b;
+    fp2_load(&x, g2 + 24 * i);
+    fp2_load(&y, g2 + 24 * i + 12);
+    fp2_sqr(&t, &y);
+    fp2_sqr(&u, &x);
+    fp2_mul(&u, &u, &x);
+    fp_set(&b.c0, K_M_B);
+    fp_set(&b.c1, K_M_B);
+    fp2_add(&u, &u, &b);
+    if (!fp2_eq(&t, &u)) { status[i] = 1; return; }
+    uint64_t kx = ZKP_BLS_X;
+    Jac<Fp2Ops> q;
+    jac_mul<Fp2Ops>(&q, &x, &y, &kx, 1);
+    // psi(P) = (conj(x) * PSI_X, conj(y) * PSI_Y); compare with -[X]P
+    Fp2 px, py, k;
+    fp2_conj(&px, &x);
+    fp2_const(&k, K_M_PSI_X_0, K_M_PSI_X_1);
+    fp2_mul(&px, &px, &k);
+    fp2_conj(&py, &y);
+    fp2_const(&k, K_M_PSI_Y_0, K_M_PSI_Y_1);
+    fp2_mul(&py, &py, &k);
+    fp2_neg(&py, &py);
+    status[i] = jac_eq_affine<Fp2Ops>(&q, &px, &py) ? 0 : 2;
+}
+
+__global__ void __launch_bounds__(TPB) k_g1_mul(const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fp x, y;
+    fp_load(&x, base + stride * i);
+    fp_load(&y, base + stride * i + 6);
+    uint64_t k[4] = {sc[4 * i], sc[4 * i + 1], sc[4 * i + 2], sc[4 * i + 3]};
+    Jac<FpOps> q;
+    jac_mul<FpOps>(&q, &x, &y, k, 4);
+    Fp ax, ay;
+    bool fin = jac_to_affine<FpOps>(&ax, &ay, &q);
+    fp_store(out + 12 * i, &ax);
+    fp_store(out + 12 * i + 6, &ay);
+    if (out_inf) out_inf[i] = fin ? 0 : 1;
+}
+__global__ void __launch_bounds__(TPB) k_g2_mul(const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fp2 x, y;
+    fp2_load(&x, base + stride * i);
+    fp2_load(&y, base + stride * i + 12);
+    uint64_t k[4] = {sc[4 * i], sc[4 * i + 1], sc[4 * i + 2], sc[4 * i + 3]};
+    Jac<Fp2Ops> q;
+    jac_mul<Fp2Ops>(&q, &x, &y, k, 4);
+    Fp2 ax, ay;
+    bool fin = jac_to_affine<Fp2Ops>(&ax, &ay, &q);
+    fp2_store(out + 24 * i, &ax);
+    fp2_store(out + 24 * i + 12, &ay);
+    if (out_inf) out_inf[i] = fin ? 0 : 1;
+}
+
+// zkVM precompile shape: op 0 = mul, 1 = add on canonical operands (src/fp.rs:376,443)
+__global__ void k_fp_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp x, y, r;
+    fp_load(&x, a + 6 * i);
+    fp_load(&y, b + 6 * i);
+    if (op == 0) fp_mul(&r, &x, &y); else fp_add(&r, &x, &y);
+    fp_store(out + 6 * i, &r);
+}
+
+// every 6-limb element of a wire buffer must be < p
+__global__ void k_check_canonical(const uint64_t* a, size_t n_fp, int* bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_fp) return;
+    if (!fp_wire_is_canonical(a + 6 * i)) atomicOr(bad, 1);
+}
+
+}  // namespace
+
+// =============================================================================== context
+struct zkp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int validate = 0;
+    int kernel = ZKP_KERNEL_AUTO;
+    std::string err;
+    // grow-only device workspace for the host-pointer API
+    void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int* d_flag = nullptr;
+    hipDeviceProp_t prop;
+    zkp::CoopState coop;
+};
+
+namespace {
+
+static const uint64_t GT_IDENTITY[72] = {1};
+
+#define HIPCHK(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                    \
+            return e__ == hipErrorOutOfMemory ? ZKP_ERR_OOM : ZKP_ERR_HIP;                      \
+        }                                                                                       \
+    } while (0)
+
+int ensure(zkp_ctx* c, int slot, size_t bytes) {
+    if (bytes <= c->cap[slot]) return ZKP_OK;
+    if (c->buf[slot]) { HIPCHK(c, hipFree(c->buf[slot])); c->buf[slot] = nullptr; c->cap[slot] = 0; }
+    HIPCHK(c, hipMalloc(&c->buf[slot], bytes));
+    c->cap[slot] = bytes;
+    return ZKP_OK;
+}
+
+inline unsigned grid_for(size_t n, int tpb) { return (unsigned)((n + tpb - 1) / tpb); }
+
+int bind(zkp_ctx* c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    return ZKP_OK;
+}
+
+// ---- device-pointer implementations (shared by both API flavours)
+int miller_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
+               uint64_t* out, hipStream_t s) {
+    if (n_checks == 0) return ZKP_OK;
+    if (zkp::coop_selected(&c->coop, c->kernel))
+        return zkp::coop_miller(&c->coop, g1, g2, i1, i2, n_checks, k, out, s) == hipSuccess ? ZKP_OK : (c->err = "coop_miller launch failed", ZKP_ERR_HIP);
+    hipLaunchKernelGGL(k_miller, dim3(grid_for(n_checks, TPB)), dim3(TPB), 0, s, g1, g2, i1, i2, n_checks, k, out);
+    HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
+}
+int final_exp_dev(zkp_ctx* c, const uint64_t* f, size_t n, uint64_t* out, hipStream_t s) {
+    if (n == 0) return ZKP_OK;
+    if (zkp::coop_selected(&c->coop, c->kernel))
+        return zkp::coop_final_exp(&c->coop, f, n, out, s) == hipSuccess ? ZKP_OK : (c->err = "coop_final_exp launch failed", ZKP_ERR_HIP);
+    hipLaunchKernelGGL(k_final_exp, dim3(grid_for(n, TPB)), dim3(TPB), 0, s, f, n, out);
+    HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
+}
+int pairing_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
+                uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s) {
+    if (all_ok) {
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, all_ok, 1);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (n_checks == 0) return ZKP_OK;
+    if (zkp::coop_selected(&c->coop, c->kernel))
+        return zkp::coop_pairing(&c->coop, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok, s) == hipSuccess ? ZKP_OK : (c->err = "coop_pairing launch failed", ZKP_ERR_HIP);
+    hipLaunchKernelGGL(k_pairing, dim3(grid_for(n_checks, TPB)), dim3(TPB), 0, s, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok);
+    HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
+}
+
+// canonical-range validation of a host-API input already copied to the device
+int validate_dev(zkp_ctx* c, const uint64_t* d, size_t n_fp) {
+    if (!c->validate || n_fp == 0) return ZKP_OK;
+    HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_check_canonical, dim3(grid_for(n_fp, 256)), dim3(256), 0, c->stream, d, n_fp, c->d_flag);
+    HIPCHK(c, hipGetLastError());
+    int bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bad) { c->err = "input limbs >= p"; return ZKP_ERR_NONCANONICAL; }
+    return ZKP_OK;
+}
+
+struct Staged { const uint64_t *g1, *g2; const uint8_t *i1, *i2; };
+
+// copy a (g1,g2,inf1,inf2) pair batch to workspace slots 0..3
+int stage_pairs(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t np, Staged* st) {
+    int rc;
+    if ((rc = ensure(c, 0, np * 96)) || (rc = ensure(c, 1, np * 192))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->buf[0], g1, np * 96, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->buf[1], g2, np * 192, hipMemcpyHostToDevice, c->stream));
+    st->g1 = (const uint64_t*)c->buf[0];
+    st->g2 = (const uint64_t*)c->buf[1];
+    st->i1 = st->i2 = nullptr;
+    if (inf1) {
+        if ((rc = ensure(c, 2, np))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->buf[2], inf1, np, hipMemcpyHostToDevice, c->stream));
+        st->i1 = (const uint8_t*)c->buf[2];
+    }
+    if (inf2) {
+        if ((rc = ensure(c, 3, np))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->buf[3], inf2, np, hipMemcpyHostToDevice, c->stream));
+        st->i2 = (const uint8_t*)c->buf[3];
+    }
+    if ((rc = validate_dev(c, st->g1, np * 2)) || (rc = validate_dev(c, st->g2, np * 4))) return rc;
+    return ZKP_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int zkp_abi_version(void) { return 1; }
+
+const char* zkp_strerror(int status) {
+    switch (status) {
+        case ZKP_OK: return "ok";
+        case ZKP_ERR_ARG: return "bad argument";
+        case ZKP_ERR_NO_DEVICE: return "no usable HIP device";
+        case ZKP_ERR_HIP: return "HIP runtime error";
+        case ZKP_ERR_NONCANONICAL: return "non-canonical field element in input";
+        case ZKP_ERR_OOM: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+
+const uint64_t* zkp_gt_identity(void) { return GT_IDENTITY; }
+
+int zkp_init(int device, zkp_ctx** out_ctx) {
+    if (!out_ctx) return ZKP_ERR_ARG;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZKP_ERR_NO_DEVICE;
+    zkp_ctx* c = new (std::nothrow) zkp_ctx();
+    if (!c) return ZKP_ERR_OOM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess || hipMalloc((void**)&c->d_flag, 2 * sizeof(int)) != hipSuccess) {
+        delete c;
+        return ZKP_ERR_NO_DEVICE;
+    }
+    if (zkp::coop_init(&c->coop, c->prop) != hipSuccess) {
+        delete c;
+        return ZKP_ERR_HIP;
+    }
+    const char* env = getenv("ZKP_KERNEL");
+    if (env) {
+        if (!strcmp(env, "thread")) c->kernel = ZKP_KERNEL_THREAD;
+        else if (!strcmp(env, "coop")) c->kernel = ZKP_KERNEL_COOP;
+    }
+    *out_ctx = c;
+    return ZKP_OK;
+}
+
+void zkp_free(zkp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    zkp::coop_free(&c->coop);
+    for (int i = 0; i < 8; i++)
+        if (c->buf[i]) (void)hipFree(c->buf[i]);
+    if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* zkp_last_error(const zkp_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+int zkp_set_validate(zkp_ctx* c, int on) { if (!c) return ZKP_ERR_ARG; c->validate = on ? 1 : 0; return ZKP_OK; }
+int zkp_set_kernel(zkp_ctx* c, int kind) {
+    if (!c || kind < ZKP_KERNEL_AUTO || kind > ZKP_KERNEL_COOP) return ZKP_ERR_ARG;
+    if (kind == ZKP_KERNEL_COOP && !c->coop.available) { c->err = "cooperative kernels not available"; return ZKP_ERR_ARG; }
+    c->kernel = kind;
+    return ZKP_OK;
+}
+int zkp_device_info(const zkp_ctx* c, int* cus, int* clock_khz, char* name, size_t name_len) {
+    if (!c) return ZKP_ERR_ARG;
+    if (cus) *cus = c->prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = c->prop.clockRate;
+    if (name && name_len) { strncpy(name, c->prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    return ZKP_OK;
+}
+
+// ---------------------------------------------------------------- device-pointer API
+#define S(stream) ((hipStream_t)(stream))
+int zkp_pairing_batch_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n, void* out, void* stream) {
+    if (!c || (n && (!g1 || !g2 || !out))) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    return pairing_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n, 1, (uint64_t*)out, nullptr, nullptr, S(stream));
+}
+int zkp_multi_miller_loop_batch_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n_checks, size_t k,
+                                    void* out, void* stream) {
+    if (!c || (n_checks && (!out || (k && (!g1 || !g2))))) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    return miller_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n_checks, k, (uint64_t*)out, S(stream));
+}
+int zkp_final_exponentiation_batch_dev(zkp_ctx* c, const void* f, size_t n, void* out, void* stream) {
+    if (!c || (n && (!f || !out))) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    return final_exp_dev(c, (const uint64_t*)f, n, (uint64_t*)out, S(stream));
+}
+int zkp_pairing_check_batch_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n_checks, size_t k,
+                                void* ok, void* all_ok, void* stream) {
+    if (!c || (n_checks && k && (!g1 || !g2))) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    return pairing_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n_checks, k, nullptr, (uint8_t*)ok,
+                       (int*)all_ok, S(stream));
+}
+int zkp_pairing_gt_check_batch_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n_checks, size_t k,
+                                   void* out_gt, void* ok, void* all_ok, void* stream) {
+    if (!c || (n_checks && k && (!g1 || !g2))) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    return pairing_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n_checks, k, (uint64_t*)out_gt,
+                       (uint8_t*)ok, (int*)all_ok, S(stream));
+}
+int zkp_g1_is_valid_batch_dev(zkp_ctx* c, const void* g1, const void* inf, size_t n, void* status, void* stream) {
+    if (!c || (n && (!g1 || !status))) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!n) return ZKP_OK;
+    hipLaunchKernelGGL(k_g1_valid, dim3(grid_for(n, TPB)), dim3(TPB), 0, S(stream), (const uint64_t*)g1, (const uint8_t*)inf, n, (uint8_t*)status);
+    HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
+}
+int zkp_g2_is_valid_batch_dev(zkp_ctx* c, const void* g2, const void* inf, size_t n, void* status, void* stream) {
+    if (!c || (n && (!g2 || !status))) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!n) return ZKP_OK;
+    hipLaunchKernelGGL(k_g2_valid, dim3(grid_for(n, TPB)), dim3(TPB), 0, S(stream), (const uint64_t*)g2, (const uint8_t*)inf, n, (uint8_t*)status);
+    HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
+}
+int zkp_g1_mul_batch_dev(zkp_ctx* c, const void* base, size_t stride, const void* sc, size_t n, void* out, void* out_inf, void* stream) {
+    if (!c || (n && (!base || !sc || !out)) || (stride != 0 && stride != 12)) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!n) return ZKP_OK;
+    hipLaunchKernelGGL(k_g1_mul, dim3(grid_for(n, TPB)), dim3(TPB), 0, S(stream), (const uint64_t*)base, stride, (const uint64_t*)sc, n, (uint64_t*)out, (uint8_t*)out_inf);
+    HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
+}
+int zkp_g2_mul_batch_dev(zkp_ctx* c, const void* base, size_t stride, const void* sc, size_t n, void* out, void* out_inf, void* stream) {
+    if (!c || (n && (!base || !sc || !out)) || (stride != 0 && stride != 24)) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!n) return ZKP_OK;
+    hipLaunchKernelGGL(k_g2_mul, dim3(grid_for(n, TPB)), dim3(TPB), 0, S(stream), (const uint64_t*)base, stride, (const uint64_t*)sc, n, (uint64_t*)out, (uint8_t*)out_inf);
+    HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
+}
+
+// ---------------------------------------------------------------- host-pointer API
+int zkp_pairing_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n, uint64_t* out_gt) {
+    if (!c || (n && (!g1 || !g2 || !out_gt))) return ZKP_ERR_ARG;
+    if (!n) return ZKP_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    Staged st;
+    if ((rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st)) || (rc = ensure(c, 4, n * 576))) return rc;
+    if ((rc = pairing_dev(c, st.g1, st.g2, st.i1, st.i2, n, 1, (uint64_t*)c->buf[4], nullptr, nullptr, c->stream))) return rc;
+    HIPCHK(c, hipMemcpyAsync(out_gt, c->buf[4], n * 576, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZKP_OK;
+}
+int zkp_multi_miller_loop_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks,
+                                size_t k, uint64_t* out_ml) {
+    if (!c || (n_checks && (!out_ml || (k && (!g1 || !g2))))) return ZKP_ERR_ARG;
+    if (!n_checks) return ZKP_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    Staged st = {nullptr, nullptr, nullptr, nullptr};
+    if (k && (rc = stage_pairs(c, g1, g2, inf1, inf2, n_checks * k, &st))) return rc;
+    if ((rc = ensure(c, 4, n_checks * 576))) return rc;
+    if ((rc = miller_dev(c, st.g1, st.g2, st.i1, st.i2, n_checks, k, (uint64_t*)c->buf[4], c->stream))) return rc;
+    HIPCHK(c, hipMemcpyAsync(out_ml, c->buf[4], n_checks * 576, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZKP_OK;
+}
+int zkp_final_exponentiation_batch(zkp_ctx* c, const uint64_t* f, size_t n, uint64_t* out_gt) {
+    if (!c || (n && (!f || !out_gt))) return ZKP_ERR_ARG;
+    if (!n) return ZKP_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    if ((rc = ensure(c, 5, n * 576)) || (rc = ensure(c, 4, n * 576))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->buf[5], f, n * 576, hipMemcpyHostToDevice, c->stream));
+    if ((rc = validate_dev(c, (const uint64_t*)c->buf[5], n * 12))) return rc;
+    if ((rc = final_exp_dev(c, (const uint64_t*)c->buf[5], n, (uint64_t*)c->buf[4], c->stream))) return rc;
+    HIPCHK(c, hipMemcpyAsync(out_gt, c->buf[4], n * 576, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZKP_OK;
+}
+int zkp_pairing_check_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks,
+                            size_t k, uint8_t* ok, int* all_ok) {
+    if (!c || (n_checks && k && (!g1 || !g2))) return ZKP_ERR_ARG;
+    if (all_ok) *all_ok = 1;
+    if (!n_checks) return ZKP_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    Staged st = {nullptr, nullptr, nullptr, nullptr};
+    if (k && (rc = stage_pairs(c, g1, g2, inf1, inf2, n_checks * k, &st))) return rc;
+    if ((rc = ensure(c, 6, n_checks))) return rc;
+    if ((rc = pairing_dev(c, st.g1, st.g2, st.i1, st.i2, n_checks, k, nullptr, (uint8_t*)c->buf[6], c->d_flag + 1, c->stream))) return rc;
+    if (ok) HIPCHK(c, hipMemcpyAsync(ok, c->buf[6], n_checks, hipMemcpyDeviceToHost, c->stream));
+    int flag = 1;
+    HIPCHK(c, hipMemcpyAsync(&flag, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (all_ok) *all_ok = flag;
+    return ZKP_OK;
+}
+static int valid_host(zkp_ctx* c, int which, const uint64_t* pts, const uint8_t* inf, size_t n, uint8_t* status) {
+    if (!c || (n && (!pts || !status))) return ZKP_ERR_ARG;
+    if (!n) return ZKP_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    size_t sz = which == 1 ? 96 : 192;
+    if ((rc = ensure(c, 0, n * sz)) || (rc = ensure(c, 6, n))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->buf[0], pts, n * sz, hipMemcpyHostToDevice, c->stream));
+    const uint8_t* di = nullptr;
+    if (inf) {
+        if ((rc = ensure(c, 2, n))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->buf[2], inf, n, hipMemcpyHostToDevice, c->stream));
+        di = (const uint8_t*)c->buf[2];
+    }
+    if ((rc = validate_dev(c, (const uint64_t*)c->buf[0], n * sz / 48))) return rc;
+    rc = which == 1 ? zkp_g1_is_valid_batch_dev(c, c->buf[0], di, n, c->buf[6], c->stream)
+                    : zkp_g2_is_valid_batch_dev(c, c->buf[0], di, n, c->buf[6], c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(status, c->buf[6], n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZKP_OK;
+}
+int zkp_g1_is_valid_batch(zkp_ctx* c, const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* status) { return valid_host(c, 1, g1, inf, n, status); }
+int zkp_g2_is_valid_batch(zkp_ctx* c, const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status) { return valid_host(c, 2, g2, inf, n, status); }
+
+static int mul_host(zkp_ctx* c, int which, const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf) {
+    size_t w = which == 1 ? 12 : 24;
+    if (!c || (n && (!base || !sc || !out)) || (stride != 0 && stride != w)) return ZKP_ERR_ARG;
+    if (!n) return ZKP_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    size_t nb = stride ? n : 1;
+    if ((rc = ensure(c, 0, nb * w * 8)) || (rc = ensure(c, 1, n * 32)) || (rc = ensure(c, 4, n * w * 8)) || (rc = ensure(c, 6, n))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->buf[0], base, nb * w * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->buf[1], sc, n * 32, hipMemcpyHostToDevice, c->stream));
+    if ((rc = validate_dev(c, (const uint64_t*)c->buf[0], nb * w / 6))) return rc;
+    rc = which == 1 ? zkp_g1_mul_batch_dev(c, c->buf[0], stride, c->buf[1], n, c->buf[4], c->buf[6], c->stream)
+                    : zkp_g2_mul_batch_dev(c, c->buf[0], stride, c->buf[1], n, c->buf[4], c->buf[6], c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->buf[4], n * w * 8, hipMemcpyDeviceToHost, c->stream));
+    if (out_inf) HIPCHK(c, hipMemcpyAsync(out_inf, c->buf[6], n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZKP_OK;
+}
+int zkp_g1_mul_batch(zkp_ctx* c, const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf) {
+    return mul_host(c, 1, base, stride, sc, n, out, out_inf);
+}
+int zkp_g2_mul_batch(zkp_ctx* c, const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf) {
+    return mul_host(c, 2, base, stride, sc, n, out, out_inf);
+}
+int zkp_fp_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    if (!c || (op != 0 && op != 1) || (n && (!a || !b || !out))) return ZKP_ERR_ARG;
+    if (!n) return ZKP_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    if ((rc = ensure(c, 0, n * 48)) || (rc = ensure(c, 1, n * 48)) || (rc = ensure(c, 4, n * 48))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->buf[0], a, n * 48, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->buf[1], b, n * 48, hipMemcpyHostToDevice, c->stream));
+    if ((rc = validate_dev(c, (const uint64_t*)c->buf[0], n)) || (rc = validate_dev(c, (const uint64_t*)c->buf[1], n))) return rc;
+    hipLaunchKernelGGL(k_fp_op, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, op, (const uint64_t*)c->buf[0], (const uint64_t*)c->buf[1], n, (uint64_t*)c->buf[4]);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->buf[4], n * 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZKP_OK;
+}
+
+int zkp_time_pairing_dev(zkp_ctx* c, const void* g1, const void* g2, size_t n, void* out, int reps, float* avg_ms) {
+    if (!c || !g1 || !g2 || !out || reps <= 0 || !avg_ms) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; r++)
+        if ((rc = pairing_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, nullptr, nullptr, n, 1, (uint64_t*)out, nullptr, nullptr, c->stream))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *avg_ms = ms / reps;
+    return ZKP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+"""Batched engine: thin, typed wrapper over the C ABI (one PairingEngine == one zkp_ctx == one GPU).
+
+Array conventions (numpy uint64 or torch int64/uint64-viewed tensors, C-contiguous):
+  g1 (n,12)  g2 (n,24)  inf (n,) uint8  fp12/Gt (n,72)  scalars (n,4)
+Host numpy arrays go through the host-pointer entry points (copy in / copy out); torch tensors
+that live on the engine's GPU go through the *_dev entry points and never leave HBM."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+KERNEL_AUTO, KERNEL_THREAD, KERNEL_COOP = 0, 1, 2
+
+
+def _np(a, cols, dtype=np.uint64):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class PairingEngine:
+    def __init__(self, device=0, kernel=None, validate=False):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self._lib.zkp_init(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise _lib.ZkpError(rc, "zkp_init(device=%d)" % device)
+        self._h = h
+        self.device = int(device)
+        if validate:
+            self._chk(self._lib.zkp_set_validate(self._h, 1))
+        if kernel is not None:
+            self.set_kernel(kernel)
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            raise _lib.ZkpError(rc, self._lib.zkp_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.zkp_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_kernel(self, kind):
+        kind = {"auto": 0, "thread": 1, "coop": 2}.get(kind, kind)
+        self._chk(self._lib.zkp_set_kernel(self._h, int(kind)))
+
+    def set_validate(self, on):
+        self._chk(self._lib.zkp_set_validate(self._h, 1 if on else 0))
+
+    def device_info(self):
+        cus, clk = ctypes.c_int(), ctypes.c_int()
+        name = ctypes.create_string_buffer(64)
+        self._chk(self._lib.zkp_device_info(self._h, ctypes.byref(cus), ctypes.byref(clk), name, 64))
+        return {"cus": cus.value, "clock_khz": clk.value, "arch": name.value.decode()}
+
+    @staticmethod
+    def gt_identity():
+        p = _lib.load().zkp_gt_identity()
+        return np.array([p[i] for i in range(72)], dtype=np.uint64)
+
+    # ------------------------------------------------------------------ host-array API
+    def pairing(self, g1, g2, inf1=None, inf2=None):
+        """out[i] = pairing(g1[i], g2[i])  -> (n,72) canonical Gt"""
+        if _is_torch(g1):
+            return self._pairing_t(g1, g2, inf1, inf2)
+        g1, g2 = _np(g1, 12), _np(g2, 24)
+        n = g1.shape[0]
+        assert g2.shape[0] == n
+        i1 = None if inf1 is None else _np(inf1, None, np.uint8)
+        i2 = None if inf2 is None else _np(inf2, None, np.uint8)
+        out = np.empty((n, 72), dtype=np.uint64)
+        self._chk(self._lib.zkp_pairing_batch(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n, _ptr(out)))
+        return out
+
+    def multi_miller_loop(self, g1, g2, k, inf1=None, inf2=None):
+        """groups of k consecutive pairs -> (n_checks,72) MillerLoopResult"""
+        if _is_torch(g1):
+            return self._miller_t(g1, g2, k, inf1, inf2)
+        g1, g2 = _np(g1, 12), _np(g2, 24)
+        n = g1.shape[0]
+        assert g2.shape[0] == n and k > 0 and n % k == 0
+        i1 = None if inf1 is None else _np(inf1, None, np.uint8)
+        i2 = None if inf2 is None else _np(inf2, None, np.uint8)
+        out = np.empty((n // k, 72), dtype=np.uint64)
+        self._chk(self._lib.zkp_multi_miller_loop_batch(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n // k, k, _ptr(out)))
+        return out
+
+    def final_exponentiation(self, f):
+        if _is_torch(f):
+            return self._fexp_t(f)
+        f = _np(f, 72)
+        out = np.empty_like(f)
+        self._chk(self._lib.zkp_final_exponentiation_batch(self._h, _ptr(f), f.shape[0], _ptr(out)))
+        return out
+
+    def pairing_check(self, g1, g2, k, inf1=None, inf2=None):
+        """-> (ok bytes (n_checks,), all_ok bool): prod_j e(g1[c*k+j], g2[c*k+j]) == Gt::identity()"""
+        if _is_torch(g1):
+            return self._check_t(g1, g2, k, inf1, inf2)
+        g1, g2 = _np(g1, 12), _np(g2, 24)
+        n = g1.shape[0]
+        assert g2.shape[0] == n and k > 0 and n % k == 0
+        i1 = None if inf1 is None else _np(inf1, None, np.uint8)
+        i2 = None if inf2 is None else _np(inf2, None, np.uint8)
+        ok = np.empty(n // k, dtype=np.uint8)
+        allok = ctypes.c_int(1)
+        self._chk(self._lib.zkp_pairing_check_batch(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n // k, k, _ptr(ok), ctypes.byref(allok)))
+        return ok, bool(allok.value)
+
+    def g1_is_valid(self, g1, inf=None):
+        if _is_torch(g1):
+            return self._valid_t(g1, inf, 1)
+        g1 = _np(g1, 12)
+        i = None if inf is None else _np(inf, None, np.uint8)
+        st = np.empty(g1.shape[0], dtype=np.uint8)
+        self._chk(self._lib.zkp_g1_is_valid_batch(self._h, _ptr(g1), _ptr(i), g1.shape[0], _ptr(st)))
+        return st
+
+    def g2_is_valid(self, g2, inf=None):
+        if _is_torch(g2):
+            return self._valid_t(g2, inf, 2)
+        g2 = _np(g2, 24)
+        i = None if inf is None else _np(inf, None, np.uint8)
+        st = np.empty(g2.shape[0], dtype=np.uint8)
+        self._chk(self._lib.zkp_g2_is_valid_batch(self._h, _ptr(g2), _ptr(i), g2.shape[0], _ptr(st)))
+        return st
+
+    def g1_mul(self, base, scalars):
+        """[k_i] base_i; base (12,) broadcasts. -> (points (n,12), inf (n,))"""
+        if _is_torch(scalars):
+            return self._mul_t(base, scalars, 1)
+        sc = _np(scalars, 4)
+        base = _np(base, 12)
+        n = sc.shape[0]
+        stride = 0 if base.shape[0] == 1 and n != 1 else 12
+        assert stride == 0 or base.shape[0] == n
+        out, oi = np.empty((n, 12), dtype=np.uint64), np.empty(n, dtype=np.uint8)
+        self._chk(self._lib.zkp_g1_mul_batch(self._h, _ptr(base), stride, _ptr(sc), n, _ptr(out), _ptr(oi)))
+        return out, oi
+
+    def g2_mul(self, base, scalars):
+        if _is_torch(scalars):
+            return self._mul_t(base, scalars, 2)
+        sc = _np(scalars, 4)
+        base = _np(base, 24)
+        n = sc.shape[0]
+        stride = 0 if base.shape[0] == 1 and n != 1 else 24
+        assert stride == 0 or base.shape[0] == n
+        out, oi = np.empty((n, 24), dtype=np.uint64), np.empty(n, dtype=np.uint8)
+        self._chk(self._lib.zkp_g2_mul_batch(self._h, _ptr(base), stride, _ptr(sc), n, _ptr(out), _ptr(oi)))
+        return out, oi
+
+    def fp_op(self, op, a, b):
+        """zkVM-precompile-shaped batched field op: op 0 = mul, 1 = add (reference src/fp.rs:376,443)."""
+        a, b = _np(a, 6), _np(b, 6)
+        out = np.empty_like(a)
+        self._chk(self._lib.zkp_fp_op_batch(self._h, int(op), _ptr(a), _ptr(b), a.shape[0], _ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ torch (device-resident) API
+    def _t_check(self, t, cols):
+        import torch
+        assert t.is_cuda and t.device.index == self.device and t.is_contiguous(), "tensor must be contiguous on cuda:%d" % self.device
+        assert t.dtype in (torch.int64, torch.uint64, torch.uint8)
+        if cols is not None:
+            assert t.numel() % cols == 0
+        return t
+
+    @staticmethod
+    def _tp(t):
+        return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _stream():
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _pairing_t(self, g1, g2, inf1, inf2, out=None):
+        import torch
+        self._t_check(g1, 12), self._t_check(g2, 24)
+        n = g1.numel() // 12
+        if out is None:
+            out = torch.empty((n, 72), dtype=g1.dtype, device=g1.device)
+        self._chk(self._lib.zkp_pairing_batch_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), n, self._tp(out), self._stream()))
+        return out
+
+    def _miller_t(self, g1, g2, k, inf1, inf2):
+        import torch
+        self._t_check(g1, 12), self._t_check(g2, 24)
+        n = g1.numel() // 12
+        assert n % k == 0
+        out = torch.empty((n // k, 72), dtype=g1.dtype, device=g1.device)
+        self._chk(self._lib.zkp_multi_miller_loop_batch_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), n // k, k, self._tp(out), self._stream()))
+        return out
+
+    def _fexp_t(self, f):
+        import torch
+        self._t_check(f, 72)
+        out = torch.empty_like(f)
+        self._chk(self._lib.zkp_final_exponentiation_batch_dev(self._h, self._tp(f), f.numel() // 72, self._tp(out), self._stream()))
+        return out
+
+    def _check_t(self, g1, g2, k, inf1, inf2):
+        import torch
+        self._t_check(g1, 12), self._t_check(g2, 24)
+        n = g1.numel() // 12
+        assert n % k == 0
+        ok = torch.empty(n // k, dtype=torch.uint8, device=g1.device)
+        allok = torch.empty(1, dtype=torch.int32, device=g1.device)
+        self._chk(self._lib.zkp_pairing_check_batch_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), n // k, k, self._tp(ok), self._tp(allok), self._stream()))
+        return ok, allok
+
+    def pairing_gt_check(self, g1, g2, k, out_gt, ok, all_ok, inf1=None, inf2=None):
+        """device tensors only: Gt out + ok bytes + AND flag in one fused pass (bench step)."""
+        self._t_check(g1, 12), self._t_check(g2, 24)
+        n = g1.numel() // 12
+        self._chk(self._lib.zkp_pairing_gt_check_batch_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), n // k, k,
+                                                           self._tp(out_gt), self._tp(ok), self._tp(all_ok), self._stream()))
+
+    def _valid_t(self, pts, inf, which):
+        import torch
+        cols = 12 if which == 1 else 24
+        self._t_check(pts, cols)
+        n = pts.numel() // cols
+        st = torch.empty(n, dtype=torch.uint8, device=pts.device)
+        fn = self._lib.zkp_g1_is_valid_batch_dev if which == 1 else self._lib.zkp_g2_is_valid_batch_dev
+        self._chk(fn(self._h, self._tp(pts), self._tp(inf), n, self._tp(st), self._stream()))
+        return st
+
+    def _mul_t(self, base, scalars, which):
+        import torch
+        cols = 12 if which == 1 else 24
+        self._t_check(scalars, 4)
+        n = scalars.numel() // 4
+        if not _is_torch(base):
+            base = torch.from_numpy(np.ascontiguousarray(base, dtype=np.uint64).view(np.int64)).to(scalars.device)
+        base = base.contiguous().view(-1)
+        self._t_check(base, cols)
+        stride = 0 if base.numel() == cols and n != 1 else cols
+        out = torch.empty((n, cols), dtype=scalars.dtype, device=scalars.device)
+        oi = torch.empty(n, dtype=torch.uint8, device=scalars.device)
+        fn = self._lib.zkp_g1_mul_batch_dev if which == 1 else self._lib.zkp_g2_mul_batch_dev
+        self._chk(fn(self._h, self._tp(base), stride, self._tp(scalars), n, self._tp(out), self._tp(oi), self._stream()))
+        return out, oi
+
+    def time_pairing(self, g1, g2, out, reps):
+        """avg ms per launch of the fused pairing kernel, HIP events on the engine's own stream."""
+        self._t_check(g1, 12), self._t_check(g2, 24), self._t_check(out, 72)
+        ms = ctypes.c_float()
+        self._chk(self._lib.zkp_time_pairing_dev(self._h, self._tp(g1), self._tp(g2), g1.numel() // 12, self._tp(out), int(reps), ctypes.byref(ms)))
+        return ms.value
