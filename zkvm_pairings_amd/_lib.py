@@ -64,6 +64,13 @@ def load():
             raise ImportError(
                 "%s is missing: build it with `make -C zkvm_pairings_amd/csrc` (or __graft_entry__.build()). "
                 "There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as the
+        # system one).  Device pointers and streams are shared with torch tensors, so torch's copy must
+        # be the one that is loaded first; without torch the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI lacks a declared symbol

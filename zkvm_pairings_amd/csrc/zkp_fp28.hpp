@@ -1,0 +1,157 @@
+// zkp_fp28.hpp -- carry-free field core of the lane-cooperative family (gfx950).
+//
+// Why this representation: on gfx950 v_add_co/v_addc (carry in/out through an SGPR pair) issue at
+// the same ~4 cycles/wave/SIMD as v_mad_u64_u32, while a carry-less v_add_u32 costs ~1.3 (measured
+// by tools/ubench_valu.hip).  So a 12x32-bit CIOS multiply spends more issue slots on carries than
+// on multiplies.  Here an Fp element is 14 signed limbs of 28 bits ("balanced": |limb| <~ 2^27):
+//   * a product is 196 v_mad_i64_i32 into 27 signed 64-bit column accumulators - no carries;
+//   * several products (a bilinear form) accumulate into the SAME columns and share ONE Montgomery
+//     reduction (lazy reduction): sum_t a_t*b_t needs 14*sum_t(La_t*Lb_t)*2^54 < 2^63, i.e.
+//     sum_t La_t*Lb_t <= 32 where L is the limb bound in units of 2^27;
+//   * add/sub/neg are limb-wise v_add/v_sub with no carry and no modular correction;
+//   * Montgomery radix R = 2^392 ~ 2^11 p, so values may drift in (-8p, 8p) and a reduced product of
+//     inputs |a|,|b| < 8p is back in (-0.04p, 1.04p): no conditional subtraction anywhere.
+// Canonical limbs are produced only at the wire (fp28_to_wire).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "zkp_constants28.h"
+
+namespace zkp28 {
+
+constexpr int NL = 14;
+constexpr int W = 28;
+constexpr int32_t MASK = (1 << W) - 1;
+
+struct Fp28 { int32_t l[NL]; };
+struct Acc { int64_t c[2 * NL]; };  // columns 0..26 (+ c[27] as the carry sink)
+
+__device__ __constant__ const int32_t K28_P[NL] = {ZKP28_P_LIMBS};
+#define ZKP28_DECL(name, ...) __device__ __constant__ const int32_t K28_##name[14] = {__VA_ARGS__};
+ZKP28_CONST_LIST(ZKP28_DECL)
+#undef ZKP28_DECL
+
+__device__ __forceinline__ void acc_zero(Acc& a) {
+#pragma unroll
+    for (int i = 0; i < 2 * NL; i++) a.c[i] = 0;
+}
+
+// acc += a * b  (schoolbook, 196 v_mad_i64_i32)
+__device__ __forceinline__ void acc_mul(Acc& acc, const int32_t* a, const int32_t* b) {
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+#pragma unroll
+        for (int j = 0; j < NL; j++) acc.c[i + j] += (int64_t)a[i] * (int64_t)b[j];
+}
+
+// sign-extended low 28 bits: value in [-2^27, 2^27)
+__device__ __forceinline__ int32_t lo28s(int64_t v) { return ((int32_t)((uint32_t)v << 4)) >> 4; }
+
+// Montgomery reduction of the accumulated columns (divides by 2^392) followed by carry
+// normalisation to balanced limbs.  Result value = acc * 2^-392 mod p, in (acc/R, acc/R + p).
+__device__ __forceinline__ void acc_reduce(int32_t* out, Acc& acc) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        uint32_t m = ((uint32_t)acc.c[i] * ZKP28_PINV) & (uint32_t)MASK;
+#pragma unroll
+        for (int j = 0; j < NL; j++) acc.c[i + j] += (int64_t)(int32_t)m * (int64_t)K28_P[j];
+        acc.c[i + 1] += acc.c[i] >> W;  // low 28 bits of c[i] are now zero
+    }
+    int64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; k++) {
+        int64_t v = acc.c[NL + k] + carry;
+        int32_t lo = lo28s(v);
+        out[k] = lo;
+        carry = (v - lo) >> W;
+    }
+    out[NL - 1] = (int32_t)(acc.c[2 * NL - 1] + carry);
+}
+
+// one-pass weak normalisation of limb-wise sums: |in| < 2^31  ->  |out| <= 2^27 + 16
+__device__ __forceinline__ void weak_norm(int32_t* x) {
+    int32_t c[NL];
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+        c[i] = (x[i] + (1 << (W - 1))) >> W;
+        x[i] -= c[i] << W;
+    }
+#pragma unroll
+    for (int i = 1; i < NL; i++) x[i] += c[i - 1];
+}
+
+__device__ __forceinline__ void fp28_mul(Fp28& r, const Fp28& a, const Fp28& b) {
+    Acc acc;
+    acc_zero(acc);
+    acc_mul(acc, a.l, b.l);
+    acc_reduce(r.l, acc);
+}
+
+// ---- wire (6 x u64 canonical) <-> Fp28 Montgomery ------------------------------------------------
+__device__ __forceinline__ void fp28_from_wire(Fp28& r, const uint64_t* src) {
+    // split the 384-bit integer into 28-bit limbs
+    uint64_t w[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) w[i] = src[i];
+    Fp28 t;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int bit = W * i, word = bit >> 6, sh = bit & 63;
+        uint64_t v = w[word] >> sh;
+        if (sh > 64 - W && word + 1 < 6) v |= w[word + 1] << (64 - sh);
+        t.l[i] = (int32_t)(v & (uint64_t)MASK);
+    }
+    Fp28 r2;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r2.l[i] = K28_R2[i];
+    fp28_mul(r, t, r2);  // a * R^2 / R = a R
+}
+
+// Montgomery Fp28 (any representative in (-8p, 8p)) -> canonical 6 x u64 in [0, p)
+__device__ __forceinline__ void fp28_to_wire(uint64_t* dst, const Fp28& a) {
+    Acc acc;
+    acc_zero(acc);
+#pragma unroll
+    for (int i = 0; i < NL; i++) acc.c[i] = a.l[i];  // a * 1
+    int32_t x[NL];
+    acc_reduce(x, acc);  // value in (-eps p, p + eps p), balanced limbs
+    // exact carry normalisation to unsigned limbs; top limb keeps the sign
+    int32_t u[NL], y[NL], z[NL];
+    int32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int32_t v = x[i] + carry;
+        if (i < NL - 1) { u[i] = v & MASK; carry = v >> W; } else u[i] = v;
+    }
+    // y = u - p, z = u + p
+    carry = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int32_t v = u[i] - K28_P[i] + carry;
+        if (i < NL - 1) { y[i] = v & MASK; carry = v >> W; } else y[i] = v;
+    }
+    carry = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int32_t v = u[i] + K28_P[i] + carry;
+        if (i < NL - 1) { z[i] = v & MASK; carry = v >> W; } else z[i] = v;
+    }
+    bool neg = u[NL - 1] < 0;      // value < 0  -> take u + p
+    bool ge = y[NL - 1] >= 0;      // value >= p -> take u - p
+    uint32_t f[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) f[i] = (uint32_t)(neg ? z[i] : (ge ? y[i] : u[i]));
+    // pack 14 x 28 bits into 6 x 64
+    uint64_t o[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int bit = W * i, word = bit >> 6, sh = bit & 63;
+        o[word] |= (uint64_t)f[i] << sh;
+        if (sh > 64 - W && word + 1 < 6) o[word + 1] |= (uint64_t)f[i] >> (64 - sh);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) dst[i] = o[i];
+}
+
+}  // namespace zkp28
