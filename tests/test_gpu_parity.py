@@ -58,6 +58,8 @@ def test_fp_op_precompile_shape(eng):
     assert o.arr_to_ints(mul) == [x * y % m.P for x, y in zip(ai, bi)]
     assert o.arr_to_ints(add) == [(x + y) % m.P for x, y in zip(ai, bi)]
     assert eng.fp_op(0, a[:0], b[:0]).shape == (0, 6)
+    # op 2: the same product through the 28-bit carry-free core of the cooperative kernel family
+    assert np.array_equal(eng.fp_op(2, a, b), mul)
 
 
 def test_scalar_mul_golden_and_oracle(eng, model_vectors):

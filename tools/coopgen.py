@@ -1,0 +1,1084 @@
+#!/usr/bin/env python3
+"""Microcode generator + bit-accurate emulator for the lane-cooperative kernel family.
+
+One "check" (k pairs, one shared Fp12 accumulator) is processed by a GROUP of 12 lanes of a
+wavefront; lane j of the group owns output coefficient j of the Fp12 value being produced
+(tower order c0.c0.c0, c0.c0.c1, ..., c1.c2.c1 == reference src/fp12.rs:13-16).  All Fp values of a
+group live in LDS slots.  A program is a list of steps; every step is executed by all lanes in
+lockstep with per-lane operands taken from tables:
+
+  MULACC  r = sum_t (+-)(A1 +- A2) * (B1 +- B2)  -> Montgomery reduce -> dst = alpha*r + beta*E
+          (A*, B*, E are slots; one reduction per output coefficient = lazy reduction)
+  LIN     dst = sum_t coef_t * slot_t  (|coef| <= 8), then one-pass weak limb normalisation
+  GLOAD   dst = global[...]   (line coefficients stream / state buffer / wire format)
+  GSTORE  global[...] = slot  (state buffer / wire format, optional Gt==identity compare)
+  LOOP n / ENDLOOP            (single level)
+
+This file (1) builds the programs from the tower formulas (symbolically: linear forms over slots,
+bilinear term lists, ksi = 1+u mixing), (2) emulates them with exactly the integer arithmetic the
+HIP interpreter performs (14 signed 28-bit limbs, 64-bit columns, R = 2^392), asserting that no
+column leaves 63 bits and no limb leaves 31 bits, and (3) writes zkvm_pairings_amd/csrc/zkp_coop_prog.inc.
+The emulator is checked against tests/golden/bls12_381_model.py in tests/test_coopgen.py.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import bls12_381_model as M  # noqa: E402
+
+P = M.P
+NL, W = 14, 28
+RADIX = 1 << (NL * W)
+RMOD = RADIX % P
+RINV = pow(RADIX, -1, P)
+PINV28 = (-pow(P, -1, 1 << W)) % (1 << W)
+P_LIMBS = [(P >> (W * i)) & ((1 << W) - 1) for i in range(NL)]
+def _balanced(v):
+    out, carry = [], 0
+    for i in range(NL):
+        d = ((v >> (W * i)) & ((1 << W) - 1)) + carry
+        if i < NL - 1 and d >= (1 << (W - 1)):
+            d -= 1 << W
+            carry = 1
+        else:
+            carry = 0
+        out.append(d)
+    return out
+
+
+P_BAL = _balanced(P)                      # balanced limbs of p (|limb| <= 2^27), used by the value renormalisation
+VRED_SHIFT_IN, VRED_SHIFT_OUT = 9, 24
+VRED_C = round((1 << (VRED_SHIFT_IN + VRED_SHIFT_OUT)) / P_BAL[NL - 1])
+G = 12                 # lanes per group
+NSLOT = 64             # group-local slots are 0..NSLOT-1; constants are NSLOT..127
+CONST_BASE = 64
+
+OP_END, OP_MULACC, OP_LIN, OP_GLOAD, OP_GSTORE, OP_LOOP, OP_ENDLOOP = 0, 1, 2, 3, 4, 5, 6
+# GLOAD / GSTORE address kinds
+K_LINE, K_STATE, K_WIRE = 0, 1, 2
+
+
+# ------------------------------------------------------------------------------------------ constants region
+def _const_table():
+    """name -> true field value (NOT Montgomery); index in the table = slot - CONST_BASE."""
+    g = [M.f2_pow(M.XI, i * (P - 1) // 6) for i in range(6)]
+    t = [("ZERO", 0), ("ONE", 1)]
+    # Frobenius^j coefficients gamma_{j,i} = gamma_i^(1 + p + ... + p^(j-1)) for w^i, j = 1, 2, 3
+    for j in (1, 2, 3):
+        for i in range(1, 6):
+            c = M.F2_ONE
+            for e in range(j):
+                x = g[i]
+                for _ in range(e):
+                    x = M.f2_conj(x)  # Frobenius on Fp2 = conjugation
+                c = M.f2_mul(c, x)
+            t.append(("F%d_%d_0" % (j, i), c[0]))
+            t.append(("F%d_%d_1" % (j, i), c[1]))
+    return t
+
+
+CONSTS = _const_table()
+CONST_SLOT = {name: CONST_BASE + i for i, (name, _) in enumerate(CONSTS)}
+# two special "raw" constants for Montgomery conversion: their LIMBS hold R^2 mod p resp. 1
+CONST_SLOT["RAW_R2"] = CONST_BASE + len(CONSTS)
+CONST_SLOT["RAW_ONE"] = CONST_BASE + len(CONSTS) + 1
+N_CONST = len(CONSTS) + 2
+assert CONST_BASE + N_CONST <= 128
+ZERO = CONST_SLOT["ZERO"]
+
+
+# ------------------------------------------------------------------------------------------ symbolic layer
+class Lin(dict):
+    """linear form over slots: {slot: int coef}"""
+
+    @staticmethod
+    def of(slot, c=1):
+        return Lin({slot: c})
+
+    def __add__(self, o):
+        r = Lin(self)
+        for k, v in o.items():
+            r[k] = r.get(k, 0) + v
+            if r[k] == 0:
+                del r[k]
+        return r
+
+    def __neg__(self):
+        return Lin({k: -v for k, v in self.items()})
+
+    def __sub__(self, o):
+        return self + (-o)
+
+    def scale(self, c):
+        return Lin({k: v * c for k, v in self.items()}) if c else Lin()
+
+    def key(self):
+        return tuple(sorted(self.items()))
+
+
+class Bil(list):
+    """bilinear value: list of (LinA, LinB, coef)"""
+
+    def __add__(self, o):
+        return Bil(list(self) + list(o))
+
+    def __neg__(self):
+        return Bil([(a, b, -c) for a, b, c in self])
+
+    def __sub__(self, o):
+        return self + (-o)
+
+    def scale(self, k):
+        return Bil([(a, b, c * k) for a, b, c in self])
+
+
+def lin2(s0, s1):
+    return (Lin.of(s0), Lin.of(s1))
+
+
+def l2_add(x, y):
+    return (x[0] + y[0], x[1] + y[1])
+
+
+def l2_sub(x, y):
+    return (x[0] - y[0], x[1] - y[1])
+
+
+def l2_neg(x):
+    return (-x[0], -x[1])
+
+
+def l2_xi(x):
+    return (x[0] - x[1], x[0] + x[1])
+
+
+def l2_conj(x):
+    return (x[0], -x[1])
+
+
+def b2_mul(x, y):
+    """(x0 + x1 u)(y0 + y1 u) with Lin components -> (Bil, Bil)"""
+    return (Bil([(x[0], y[0], 1), (x[1], y[1], -1)]), Bil([(x[0], y[1], 1), (x[1], y[0], 1)]))
+
+
+def b2_sqr(x):
+    """(x0 + x1 u)^2 = (x0 + x1)(x0 - x1) + (2 x0) x1 u : 2 products"""
+    return (Bil([(x[0] + x[1], x[0] - x[1], 1)]), Bil([(x[0].scale(2), x[1], 1)]))
+
+
+def b2_add(x, y):
+    return (x[0] + y[0], x[1] + y[1])
+
+
+def b2_sub(x, y):
+    return (x[0] - y[0], x[1] - y[1])
+
+
+def b2_xi(x):
+    return (x[0] - x[1], x[0] + x[1])
+
+
+def b2_scale(x, k):
+    return (x[0].scale(k), x[1].scale(k))
+
+
+def b6_mul(a, b):
+    """a, b: 3-tuples of Lin-pairs -> 3-tuple of Bil-pairs (schoolbook over Fp2, v^3 = xi)"""
+    m = [[b2_mul(a[i], b[j]) for j in range(3)] for i in range(3)]
+    c0 = b2_add(m[0][0], b2_xi(b2_add(m[1][2], m[2][1])))
+    c1 = b2_add(b2_add(m[0][1], m[1][0]), b2_xi(m[2][2]))
+    c2 = b2_add(b2_add(m[0][2], m[1][1]), m[2][0])
+    return (c0, c1, c2)
+
+
+def b6_add(x, y):
+    return tuple(b2_add(p, q) for p, q in zip(x, y))
+
+
+def b6_mul_v(x):
+    return (b2_xi(x[2]), x[0], x[1])
+
+
+def l6_add(x, y):
+    return tuple(l2_add(p, q) for p, q in zip(x, y))
+
+
+def l6_mul_v(x):
+    return (l2_xi(x[2]), x[0], x[1])
+
+
+def l6_neg(x):
+    return tuple(l2_neg(p) for p in x)
+
+
+class V12:
+    """an Fp12 value resident in 12 consecutive... (not necessarily) slots, with a sign per coefficient
+    (conjugation and negation are free views)."""
+
+    def __init__(self, slots, signs=None):
+        self.slots = list(slots)
+        self.signs = list(signs) if signs else [1] * 12
+
+    def lin(self, i):
+        return Lin.of(self.slots[i], self.signs[i])
+
+    def fp2(self, j):  # j-th Fp2 coefficient in tower order (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2)
+        return (self.lin(2 * j), self.lin(2 * j + 1))
+
+    def fp6(self, h):
+        return tuple(self.fp2(3 * h + j) for j in range(3))
+
+    def conj(self):
+        return V12(self.slots, [s if i < 6 else -s for i, s in enumerate(self.signs)])
+
+
+def flatten12(c0, c1):
+    """two Fp6 (3-tuples of pairs) -> list of 12"""
+    out = []
+    for h in (c0, c1):
+        for p in h:
+            out += [p[0], p[1]]
+    return out
+
+
+def merge_terms(bil):
+    """group by A form (summing B), then drop zero terms"""
+    by_a = {}
+    for a, b, c in bil:
+        if not a or not b or c == 0:
+            continue
+        ka = a.key()
+        # normalise the sign of A so that A and -A merge
+        first = ka[0][1]
+        if first < 0:
+            a, c = -a, -c
+            ka = a.key()
+        if ka in by_a:
+            by_a[ka] = (a, by_a[ka][1] + b.scale(c))
+        else:
+            by_a[ka] = (a, b.scale(c))
+    out = []
+    for a, b in by_a.values():
+        if b:
+            out.append((a, b))
+    # second pass: merge equal B forms (sum the A's)
+    by_b = {}
+    for a, b in out:
+        kb = b.key()
+        sgn = 1
+        if kb[0][1] < 0:
+            b, sgn = -b, -1
+            kb = b.key()
+        if kb in by_b:
+            by_b[kb] = (by_b[kb][0] + a.scale(sgn), b)
+        else:
+            by_b[kb] = (a.scale(sgn), b)
+    return [(a, b) for a, b in by_b.values() if a and b]
+
+
+def encode_form(f):
+    """Lin with <=2 slots and coefficients in {+-1} (or one slot with +-2) -> (s1, s2, sub, neg) or None"""
+    items = sorted(f.items())
+    if len(items) == 1:
+        s, c = items[0]
+        if c in (1, -1):
+            return (s, ZERO, 0, c < 0)
+        if c in (2, -2):
+            return (s, s, 0, c < 0)
+        return None
+    if len(items) == 2:
+        (s1, c1), (s2, c2) = items
+        if abs(c1) != 1 or abs(c2) != 1:
+            return None
+        if c1 > 0 and c2 > 0:
+            return (s1, s2, 0, False)
+        if c1 > 0 and c2 < 0:
+            return (s1, s2, 1, False)
+        if c1 < 0 and c2 > 0:
+            return (s2, s1, 1, False)
+        return (s1, s2, 0, True)
+    return None
+
+
+# ------------------------------------------------------------------------------------------ program builder
+class Builder:
+    def __init__(self):
+        self.steps = []
+        self.free = list(range(NSLOT - 1, -1, -1))
+        self.peak = 0
+
+    # ---- slots
+    def alloc(self, n=1):
+        assert len(self.free) >= n, "out of LDS slots"
+        r = [self.free.pop() for _ in range(n)]
+        self.peak = max(self.peak, NSLOT - len(self.free))
+        return r
+
+    def release(self, slots):
+        for s in slots:
+            assert s < NSLOT and s not in self.free
+            self.free.append(s)
+
+    def alloc12(self):
+        return V12(self.alloc(12))
+
+    # ---- raw steps
+    def lin(self, lanes):
+        """lanes: list (<=12) of (dst, Lin) ; coefficient magnitudes <= 8, <=4 terms"""
+        assert 0 < len(lanes) <= G
+        nt = max(len(f) for _, f in lanes)
+        assert 1 <= nt <= 4, nt
+        ent = []
+        for dst, f in lanes:
+            terms = sorted(f.items())
+            assert all(-8 <= c <= 8 and c != 0 for _, c in terms)
+            ent.append((dst, terms))
+        self.steps.append({"op": OP_LIN, "nt": nt, "lanes": ent})
+
+    def mulacc(self, outs):
+        """outs: list (<=12) of dict(dst=slot, bil=Bil or list of (Lin,Lin) merged, alpha=1, beta=0, e=ZERO).
+        Forms that do not fit the on-the-fly encoding are materialised by LIN pre-steps."""
+        assert 0 < len(outs) <= G
+        merged = []
+        for o in outs:
+            terms = merge_terms(o["bil"])
+            merged.append(terms)
+        # materialise awkward forms
+        temps = {}
+        pre = []
+
+        def fit(f):
+            e = encode_form(f)
+            if e is not None:
+                return f
+            k = f.key()
+            sgn = 1
+            if k[0][1] < 0:
+                k = (-f).key()
+                sgn = -1
+            if k not in temps:
+                t = self.alloc(1)[0]
+                temps[k] = t
+                pre.append((t, f.scale(sgn)))
+            return Lin.of(temps[k], sgn)
+
+        fitted = [[(fit(a), fit(b)) for a, b in terms] for terms in merged]
+        for i in range(0, len(pre), G):
+            self.lin(pre[i:i + G])
+        lanes = []
+        for o, terms in zip(outs, fitted):
+            enc = []
+            for a, b in terms:
+                ea, eb = encode_form(a), encode_form(b)
+                assert ea and eb
+                enc.append((ea[0], ea[1], ea[2], eb[0], eb[1], eb[2], bool(ea[3]) ^ bool(eb[3])))
+            lanes.append({"dst": o["dst"], "terms": enc, "alpha": o.get("alpha", 1), "beta": o.get("beta", 0), "e": o.get("e", ZERO)})
+        T = max(len(l["terms"]) for l in lanes)
+        assert T >= 1
+        epi = [(l["alpha"], l["beta"]) != (1, 0) for l in lanes]
+        assert all(epi) or not any(epi), "epilogue must be step-uniform"
+        self.steps.append({"op": OP_MULACC, "T": T, "lanes": lanes, "epi": bool(epi[0])})
+        self.release(list(temps.values()))
+        return T
+
+    def gload(self, kind, lanes, advance=0):
+        """lanes: list of (dst, index).  K_LINE: index = coefficient (0..5) of pair `pair` at the stream
+        cursor; K_STATE: index = state element; K_WIRE: index = Fp index in the wire record."""
+        self.steps.append({"op": OP_GLOAD, "kind": kind, "lanes": list(lanes), "advance": advance})
+
+    def gstore(self, kind, lanes, check_identity=False):
+        self.steps.append({"op": OP_GSTORE, "kind": kind, "lanes": list(lanes), "check": check_identity})
+
+    def loop(self, n):
+        self.steps.append({"op": OP_LOOP, "n": n})
+
+    def endloop(self):
+        self.steps.append({"op": OP_ENDLOOP})
+
+    # ---- tower macro-ops (lane j produces coefficient j).  dst is a V12 or a slot list; the result
+    # is returned as a fresh V12 over those slots (all signs +).
+    @staticmethod
+    def _slots(dst):
+        return dst.slots if isinstance(dst, V12) else list(dst)
+
+    def fp12_mul(self, dst, a, b):
+        d = self._slots(dst)
+        c0 = b6_add(b6_mul(a.fp6(0), b.fp6(0)), b6_mul_v(b6_mul(a.fp6(1), b.fp6(1))))
+        c1 = b6_add(b6_mul(a.fp6(0), b.fp6(1)), b6_mul(a.fp6(1), b.fp6(0)))
+        self.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(flatten12(c0, c1))])
+        return V12(d)
+
+    def fp12_sqr(self, dst, a):
+        """complex squaring (reference src/fp12.rs:173-184): ab = a0 a1; c0 = (a0+a1)(a0+v a1) - ab - v ab; c1 = 2ab"""
+        d = self._slots(dst)
+        a0, a1 = a.fp6(0), a.fp6(1)
+        s = l6_add(a0, a1)
+        t = l6_add(a0, l6_mul_v(a1))
+        ts = self.alloc(12)
+        forms = [c for p in s for c in p] + [c for p in t for c in p]
+        self.lin(list(zip(ts, forms)))
+        S = tuple(lin2(ts[2 * j], ts[2 * j + 1]) for j in range(3))
+        Tt = tuple(lin2(ts[6 + 2 * j], ts[6 + 2 * j + 1]) for j in range(3))
+        ab = b6_mul(a0, a1)
+        st = b6_mul(S, Tt)
+        tmp = self.alloc(12)
+        self.mulacc([{"dst": tmp[i], "bil": bl} for i, bl in enumerate(flatten12(ab, st))])
+        self.release(ts)
+        AB = tuple(lin2(tmp[2 * j], tmp[2 * j + 1]) for j in range(3))
+        ST = tuple(lin2(tmp[6 + 2 * j], tmp[6 + 2 * j + 1]) for j in range(3))
+        vab = l6_mul_v(AB)
+        c0 = tuple(l2_sub(l2_sub(ST[j], AB[j]), vab[j]) for j in range(3))
+        c1 = tuple((AB[j][0].scale(2), AB[j][1].scale(2)) for j in range(3))
+        forms = [c for p in c0 for c in p] + [c for p in c1 for c in p]
+        self.lin(list(zip(d, forms)))
+        self.release(tmp)
+        return V12(d)
+
+    def fp12_mul_by_014(self, dst, a, l0, l1, l4):
+        """a * ((l0 + l1 v) + (l4 v) w)  (reference src/fp12.rs:99-111); l* are Lin pairs"""
+        d = self._slots(dst)
+        z = (Lin(), Lin())
+        b0 = (l0, l1, z)
+        b1 = (z, l4, z)
+        # sparse operand on the A side of every term so that merge_terms groups by its 6 coefficients
+        c0 = b6_add(b6_mul(b0, a.fp6(0)), b6_mul_v(b6_mul(b1, a.fp6(1))))
+        c1 = b6_add(b6_mul(b1, a.fp6(0)), b6_mul(b0, a.fp6(1)))
+        self.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(flatten12(c0, c1))])
+        return V12(d)
+
+    def cyclotomic_sqr(self, dst, a):
+        """Granger-Scott squaring; one MULACC (T = 3) with the 3t +- 2z combination in the epilogue"""
+        d = self._slots(dst)
+        z0, z4, z3, z2, z1, z5 = (a.fp2(j) for j in range(6))
+
+        def fp4(x, y):
+            o0 = b2_add(b2_xi(b2_sqr(y)), b2_sqr(x))
+            o1 = b2_mul((x[0].scale(2), x[1].scale(2)), y)
+            return o0, o1
+
+        t0, t1 = fp4(z0, z1)
+        u0, u1 = fp4(z2, z3)
+        w0, w1 = fp4(z4, z5)
+        # z0' = 3 t0 - 2 z0 ; z4' = 3 u0 - 2 z4 ; z3' = 3 w0 - 2 z3 ; z2' = 3 xi w1 + 2 z2 ; z1' = 3 t1 + 2 z1 ; z5' = 3 u1 + 2 z5
+        res = [(t0, -2), (u0, -2), (w0, -2), (b2_xi(w1), 2), (t1, 2), (u1, 2)]
+        outs = []
+        for j, (val, beta) in enumerate(res):
+            for c in range(2):
+                i = 2 * j + c
+                outs.append({"dst": d[i], "bil": val[c], "alpha": 3, "beta": beta * a.signs[i], "e": a.slots[i]})
+        self.mulacc(outs)
+        return V12(d)
+
+    def frobenius(self, dst, a, power):
+        """TRUE Frobenius^power (power in 1..3): coefficient of w^i is conjugated `power` times and
+        multiplied by the constant F{power}_i.  Tower index j <-> w-power: (0,2,4,1,3,5)[j]."""
+        d = self._slots(dst)
+        wp = (0, 2, 4, 1, 3, 5)
+        one = Lin.of(CONST_SLOT["ONE"])
+        outs = []
+        for j in range(6):
+            x = a.fp2(j)
+            if power & 1:
+                x = l2_conj(x)
+            if wp[j] == 0:
+                val = (Bil([(x[0], one, 1)]), Bil([(x[1], one, 1)]))
+            else:
+                k = lin2(CONST_SLOT["F%d_%d_0" % (power, wp[j])], CONST_SLOT["F%d_%d_1" % (power, wp[j])])
+                val = b2_mul(x, k)
+            outs.append({"dst": d[2 * j], "bil": val[0]})
+            outs.append({"dst": d[2 * j + 1], "bil": val[1]})
+        self.mulacc(outs)
+        return V12(d)
+
+    def copy12(self, dst, a):
+        d = self._slots(dst)
+        self.lin([(d[i], a.lin(i)) for i in range(12)])
+        return V12(d)
+
+    # ---- spills to the per-check state buffer (12 elements starting at `elem`)
+    def spill(self, v, elem):
+        self.gstore(K_STATE, [(v.slots[i], elem + i) for i in range(12)])
+        self.release(v.slots)
+        return (elem, list(v.signs))
+
+    def fill(self, handle):
+        elem, signs = handle
+        s = self.alloc(12)
+        self.gload(K_STATE, [(s[i], elem + i) for i in range(12)])
+        return V12(s, signs)
+
+
+# ------------------------------------------------------------------------------------------ programs
+def miller_bits():
+    """iteration structure of the Miller loop over |x| >> 1 below its leading one: list of bools (add step?)"""
+    bits = bin(M.BLS_X >> 1)[3:]
+    return [b == "1" for b in bits]
+
+
+def n_line_steps():
+    return len(miller_bits()) + sum(miller_bits()) + 1   # 62 doublings + 5 additions + final doubling = 68
+
+
+def runs(flags):
+    """[False, False, True, False] -> [(2, True), (1, False)] : (number of plain iterations, then-has-add)"""
+    out = []
+    n = 0
+    for f in flags:
+        n += 1
+        if f:
+            out.append((n, True))
+            n = 0
+    if n:
+        out.append((n, False))
+    return out
+
+
+def emit_line_mul(b, f, k, tmp6):
+    """for each of the k pairs: load the next line (6 Fp, already scaled by P) and multiply f by it"""
+    for j in range(k):
+        b.gload(K_LINE, [(tmp6[c], (j, c)) for c in range(6)], advance=1 if j == k - 1 else 0)
+        l0 = lin2(tmp6[0], tmp6[1])
+        l1 = lin2(tmp6[2], tmp6[3])
+        l4 = lin2(tmp6[4], tmp6[5])
+        f = b.fp12_mul_by_014(f, f, l0, l1, l4)
+    return f
+
+
+def prog_miller(k, to_wire):
+    """multi_miller_loop of one check of k pairs from the precomputed line stream.
+    Line stream order per step: (c2, c1*xP, c0*yP) == the (c0, c1, c4) arguments of mul_by_014."""
+    b = Builder()
+    f = b.alloc12()
+    tmp6 = b.alloc(6)
+    one = CONST_SLOT["ONE"]
+    b.lin([(f.slots[i], Lin.of(one if i == 0 else ZERO)) for i in range(12)])
+    for n_plain, has_add in runs(miller_bits()):
+        # iterations: [dbl-line, square] * (n_plain - 1), then [dbl-line, (add-line), square]
+        body_plain = n_plain - 1 if has_add else n_plain
+        if body_plain > 0:
+            if body_plain > 1:
+                b.loop(body_plain)
+            f = emit_line_mul(b, f, k, tmp6)
+            f = b.fp12_sqr(f, f)
+            if body_plain > 1:
+                b.endloop()
+        if has_add:
+            f = emit_line_mul(b, f, k, tmp6)
+            f = emit_line_mul(b, f, k, tmp6)
+            f = b.fp12_sqr(f, f)
+    f = emit_line_mul(b, f, k, tmp6)
+    b.release(tmp6)
+    finish_output(b, f.conj(), to_wire, ST_F)
+    return b
+
+
+def finish_output(b, v, to_wire, state_base, check_identity=False):
+    t = b.alloc(12)
+    if to_wire:
+        # leave Montgomery form: reduce(v * 1); the store canonicalises and packs
+        raw1 = Lin.of(CONST_SLOT["RAW_ONE"])
+        b.mulacc([{"dst": t[i], "bil": Bil([(v.lin(i), raw1, 1)])} for i in range(12)])
+        b.gstore(K_WIRE, [(t[i], i) for i in range(12)], check_identity)
+    else:
+        b.lin([(t[i], v.lin(i)) for i in range(12)])
+        b.gstore(K_STATE, [(t[i], state_base + i) for i in range(12)])
+    b.release(t)
+
+
+def load_input(b, from_wire, state_base=0):
+    f = b.alloc12()
+    if from_wire:
+        b.gload(K_WIRE, [(f.slots[i], i) for i in range(12)])
+        r2 = Lin.of(CONST_SLOT["RAW_R2"])
+        b.mulacc([{"dst": f.slots[i], "bil": Bil([(f.lin(i), r2, 1)])} for i in range(12)])
+    else:
+        b.gload(K_STATE, [(f.slots[i], state_base + i) for i in range(12)])
+    return f
+
+
+# state buffer layout (elements of 16 dwords each, per check)
+ST_F = 0        # 12: Miller output (Montgomery Fp28)
+ST_C = 12       # 6 : Fp6-inverse cofactors C0..C2
+ST_NC = 18      # 2 : N = (N0, N1) in Fp2
+ST_N = 20       # 1 : n = N0^2 + N1^2 in Fp  (input of the batched inversion kernel)
+ST_NINV = 21    # 1 : n^-1                      (its output)
+ST_SPILL = 24   # 6 x 12 spill areas used by the hard part
+ST_SIZE = ST_SPILL + 6 * 12
+
+
+def prog_fexp_a(from_wire):
+    """first half of the final exponentiation: everything of Fp12::invert (reference src/fp12.rs:186-190,
+    src/fp6.rs:291-309, src/fp2.rs:278-296) down to the single Fp inversion."""
+    b = Builder()
+    f = load_input(b, from_wire, ST_F)
+    a0, a1 = f.fp6(0), f.fp6(1)
+    # t = a0^2 - v a1^2  (Fp6): lanes 0-5 give a0^2, lanes 6-11 give a1^2
+    sq = b.alloc(12)
+    b.mulacc([{"dst": sq[i], "bil": bl} for i, bl in enumerate(flatten12(b6_mul(a0, a0), b6_mul(a1, a1)))])
+    S0 = tuple(lin2(sq[2 * j], sq[2 * j + 1]) for j in range(3))
+    S1 = tuple(lin2(sq[6 + 2 * j], sq[6 + 2 * j + 1]) for j in range(3))
+    vS1 = l6_mul_v(S1)
+    t6 = b.alloc(6)
+    b.lin([(t6[2 * j + c], l2_sub(S0[j], vS1[j])[c]) for j in range(3) for c in range(2)])
+    b.release(sq)
+    t = tuple(lin2(t6[2 * j], t6[2 * j + 1]) for j in range(3))
+    # cofactors C0 = t0^2 - xi t1 t2 ; C1 = xi t2^2 - t0 t1 ; C2 = t1^2 - t0 t2
+    C0 = b2_sub(b2_mul(t[0], t[0]), b2_xi(b2_mul(t[1], t[2])))
+    C1 = b2_sub(b2_xi(b2_mul(t[2], t[2])), b2_mul(t[0], t[1]))
+    C2 = b2_sub(b2_mul(t[1], t[1]), b2_mul(t[0], t[2]))
+    cs = b.alloc(6)
+    b.mulacc([{"dst": cs[2 * j + c], "bil": (C0, C1, C2)[j][c]} for j in range(3) for c in range(2)])
+    C = tuple(lin2(cs[2 * j], cs[2 * j + 1]) for j in range(3))
+    # N = xi (t1 C2 + t2 C1) + t0 C0   (Fp2)
+    Nb = b2_add(b2_xi(b2_add(b2_mul(t[1], C[2]), b2_mul(t[2], C[1]))), b2_mul(t[0], C[0]))
+    ns = b.alloc(2)
+    b.mulacc([{"dst": ns[c], "bil": Nb[c]} for c in range(2)])
+    # n = N0^2 + N1^2
+    n1 = b.alloc(1)
+    b.mulacc([{"dst": n1[0], "bil": Bil([(Lin.of(ns[0]), Lin.of(ns[0]), 1), (Lin.of(ns[1]), Lin.of(ns[1]), 1)])}])
+    if from_wire:
+        b.gstore(K_STATE, [(f.slots[i], ST_F + i) for i in range(12)])
+    b.gstore(K_STATE, [(cs[i], ST_C + i) for i in range(6)] + [(ns[i], ST_NC + i) for i in range(2)] + [(n1[0], ST_N)])
+    return b
+
+
+def flush_sqr(b, v, n):
+    if n <= 0:
+        return v
+    if n > 1:
+        b.loop(n)
+    v = b.cyclotomic_sqr(v, v)
+    if n > 1:
+        b.endloop()
+    return v
+
+
+def cyc_exp(b, a):
+    """returns conj(a^|x|) in freshly allocated slots (a in the cyclotomic subgroup; MSB-first over |x|)"""
+    bits = bin(M.BLS_X)[2:]
+    r = b.copy12(b.alloc(12), a)   # leading one
+    run = 0
+    for bit in bits[1:]:
+        run += 1
+        if bit == "1":
+            r = flush_sqr(b, r, run)
+            run = 0
+            r = b.fp12_mul(r, r, a)
+    r = flush_sqr(b, r, run)
+    return r.conj()
+
+
+def prog_fexp_c(to_wire=True):
+    """second half: finish the inversion, easy part, hard part (x-chain), output Gt.  At most four Fp12
+    values are LDS-resident at any time; the rest are spilled to the per-check state buffer."""
+    b = Builder()
+    f = V12(b.alloc(12))
+    b.gload(K_STATE, [(f.slots[i], ST_F + i) for i in range(12)])
+    st = b.alloc(9)
+    b.gload(K_STATE, [(st[i], ST_C + i) for i in range(6)] + [(st[6 + i], ST_NC + i) for i in range(2)] + [(st[8], ST_NINV)])
+    C = tuple(lin2(st[2 * j], st[2 * j + 1]) for j in range(3))
+    N = lin2(st[6], st[7])
+    ninv = Lin.of(st[8])
+    # N^-1 = (N0 ninv, -N1 ninv)
+    ni = b.alloc(2)
+    b.mulacc([{"dst": ni[0], "bil": Bil([(N[0], ninv, 1)])}, {"dst": ni[1], "bil": Bil([(N[1], ninv, -1)])}])
+    NI = lin2(ni[0], ni[1])
+    # t^-1 = (C0, C1, C2) * N^-1   (Fp6)
+    ti = b.alloc(6)
+    b.mulacc([{"dst": ti[2 * j + c], "bil": b2_mul(C[j], NI)[c]} for j in range(3) for c in range(2)])
+    TI = tuple(lin2(ti[2 * j], ti[2 * j + 1]) for j in range(3))
+    b.release(st)
+    b.release(ni)
+    # f^-1 = (a0 t^-1, -a1 t^-1)
+    finv = b.alloc12()
+    b.mulacc([{"dst": finv.slots[i], "bil": bl} for i, bl in enumerate(flatten12(b6_mul(f.fp6(0), TI), b6_mul(l6_neg(f.fp6(1)), TI)))])
+    b.release(ti)
+    # easy part: u = conj(f) * f^-1 ; t2 = frob^2(u) * u
+    u = b.fp12_mul(finv, f.conj(), finv)
+    t2 = b.frobenius(f, u, 2)
+    t2 = b.fp12_mul(t2, t2, u)
+    # hard part: the upstream-shaped x-chain of DESIGN.md / SURVEY.md S6 (the products of the last
+    # lines are associated differently to bound LDS residency; exact field arithmetic => same value)
+    t1 = b.cyclotomic_sqr(u, t2).conj()
+    t3 = cyc_exp(b, t2)
+    t4 = b.cyclotomic_sqr(b.alloc(12), t3)
+    t5 = b.fp12_mul(t1, t1, t3)                 # t1's slots now hold t5
+    h4 = b.spill(t4, ST_SPILL + 0)
+    h3 = b.spill(t3, ST_SPILL + 12)
+    t1 = cyc_exp(b, t5)
+    h5 = b.spill(t5, ST_SPILL + 24)
+    t0 = cyc_exp(b, t1)
+    h1 = b.spill(t1, ST_SPILL + 36)
+    h2 = b.spill(t2, ST_SPILL + 48)
+    t6 = cyc_exp(b, t0)
+    h0 = b.spill(t0, ST_SPILL + 60)
+    t4 = b.fill(h4)
+    t6 = b.fp12_mul(t6, t6, t4)
+    b.release(t4.slots)
+    t4 = cyc_exp(b, t6)
+    t2 = b.fill(h2)
+    t5 = b.fill(h5)
+    t5 = b.fp12_mul(t5, t5.conj(), t2)
+    t4 = b.fp12_mul(t4, t4, t5)
+    b.release(t5.slots)
+    t6 = b.fp12_mul(t6, t6, t2.conj())
+    t6 = b.frobenius(t6, t6, 1)
+    t1 = b.fill(h1)
+    t1 = b.fp12_mul(t1, t1, t2)
+    b.release(t2.slots)
+    t1 = b.frobenius(t1, t1, 3)
+    t1 = b.fp12_mul(t1, t1, t6)
+    b.release(t6.slots)
+    t1 = b.fp12_mul(t1, t1, t4)
+    b.release(t4.slots)
+    t3 = b.fill(h3)
+    t0 = b.fill(h0)
+    t3 = b.fp12_mul(t3, t3, t0)
+    b.release(t0.slots)
+    t3 = b.frobenius(t3, t3, 2)
+    t3 = b.fp12_mul(t3, t3, t1)
+    b.release(t1.slots)
+    finish_output(b, t3, to_wire, ST_F, check_identity=True)
+    return b
+
+
+# ------------------------------------------------------------------------------------------ emulator (bit-accurate)
+def to_limbs_balanced(v):
+    """true integer v (|v| < 2^391) -> 14 balanced limbs"""
+    neg = v < 0
+    v = abs(v)
+    out = []
+    carry = 0
+    for i in range(NL):
+        d = ((v >> (W * i)) & ((1 << W) - 1)) + carry
+        if i < NL - 1 and d >= (1 << (W - 1)):
+            d -= 1 << W
+            carry = 1
+        else:
+            carry = 0
+        out.append(d)
+    if neg:
+        out = [-x for x in out]
+    return out
+
+
+def limbs_value(l):
+    return sum(x << (W * i) for i, x in enumerate(l))
+
+
+def mont(v):
+    return to_limbs_balanced(v % P * RMOD % P)
+
+
+def from_mont(l):
+    return limbs_value(l) * RINV % P
+
+
+def lo28s(v):
+    x = v & ((1 << W) - 1)
+    return x - (1 << W) if x >= (1 << (W - 1)) else x
+
+
+def acc_reduce(col):
+    """exactly zkp28::acc_reduce"""
+    col = list(col) + [0] * (2 * NL - len(col))
+    for i in range(NL):
+        m = ((col[i] & 0xFFFFFFFF) * PINV28) & ((1 << W) - 1)
+        for j in range(NL):
+            col[i + j] += m * P_LIMBS[j]
+            assert abs(col[i + j]) < (1 << 63), "column overflow in reduction"
+        assert col[i] & ((1 << W) - 1) == 0
+        col[i + 1] += col[i] >> W
+    out = []
+    carry = 0
+    for k in range(NL - 1):
+        v = col[NL + k] + carry
+        lo = lo28s(v)
+        out.append(lo)
+        carry = (v - lo) >> W
+    top = col[2 * NL - 1] + carry
+    assert abs(top) < (1 << 31)
+    out.append(top)
+    return out
+
+
+def weak_norm(x):
+    x = list(x)
+    c = []
+    for i in range(NL - 1):
+        assert abs(x[i]) < (1 << 31) - (1 << 27), "limb overflow before weak_norm"
+        ci = (x[i] + (1 << (W - 1))) >> W
+        c.append(ci)
+        x[i] -= ci << W
+    for i in range(1, NL):
+        x[i] += c[i - 1]
+        assert abs(x[i]) < (1 << 31)
+    return x
+
+
+def vred(x):
+    """value renormalisation, exactly as the kernel does it: q = round(top / p_top) from the top limb,
+    x -= q * p limb-wise (balanced p), weak_norm.  Input: weakly normalised limbs, |value| < ~14 p."""
+    t = x[NL - 1]
+    q = ((t >> VRED_SHIFT_IN) * VRED_C + (1 << (VRED_SHIFT_OUT - 1))) >> VRED_SHIFT_OUT
+    assert abs(q) <= 14, "value too large for vred (q = %d)" % q
+    y = [a - q * b for a, b in zip(x, P_BAL)]
+    y = weak_norm(y)
+    assert abs(limbs_value(y)) < 0.51 * P
+    return y
+
+
+def canonical_from_reduced(l):
+    v = limbs_value(l)
+    assert -P < v < 2 * P, "value out of canonicalisation range"
+    return v % P
+
+
+class Emu:
+    """one lane-group.  slots hold limb vectors.  `lines`: list of steps, each a list (per pair) of 6
+    true field values (c2, c1*xP, c0*yP); `state`/`wire_in`: dict/list of true values."""
+
+    def __init__(self, lines=None, state=None, wire_in=None):
+        self.slot = {}
+        for name, val in CONSTS:
+            self.slot[CONST_SLOT[name]] = mont(val)
+        self.slot[CONST_SLOT["RAW_R2"]] = to_limbs_balanced(RMOD * RMOD % P)
+        self.slot[CONST_SLOT["RAW_ONE"]] = [1] + [0] * (NL - 1)
+        self.lines = lines or []
+        self.cursor = 0
+        self.state = dict(state or {})     # element -> limb vector
+        self.wire_in = wire_in
+        self.wire_out = None
+        self.is_identity = None
+        self.max_col = 0
+        self.counts = {"mulacc_steps": 0, "products": 0, "lin_steps": 0, "P_blocks": 0}
+
+    def form(self, s1, s2, sub):
+        a, b = self.slot[s1], self.slot[s2]
+        return [x - y for x, y in zip(a, b)] if sub else [x + y for x, y in zip(a, b)]
+
+    def run(self, steps):
+        pc = 0
+        loop_start, loop_left = None, 0
+        while pc < len(steps):
+            st = steps[pc]
+            op = st["op"]
+            if op == OP_LOOP:
+                loop_start, loop_left = pc + 1, st["n"]
+            elif op == OP_ENDLOOP:
+                loop_left -= 1
+                if loop_left > 0:
+                    pc = loop_start
+                    continue
+            elif op == OP_MULACC:
+                self.counts["mulacc_steps"] += 1
+                self.counts["P_blocks"] += st["T"]
+                res = []
+                for ln in st["lanes"]:
+                    col = [0] * (2 * NL - 1)
+                    for (a1, a2, asub, b1, b2, bsub, neg) in ln["terms"]:
+                        a = self.form(a1, a2, asub)
+                        b = self.form(b1, b2, bsub)
+                        if neg:
+                            a = [-x for x in a]
+                        assert all(abs(x) < (1 << 31) for x in a + b)
+                        for i in range(NL):
+                            if a[i]:
+                                for j in range(NL):
+                                    col[i + j] += a[i] * b[j]
+                        self.counts["products"] += 1
+                    mx = max(abs(c) for c in col)
+                    self.max_col = max(self.max_col, mx)
+                    assert mx < (1 << 62), "column overflow in accumulation (%d bits)" % mx.bit_length()
+                    r = acc_reduce(col)
+                    e = self.slot[ln["e"]]
+                    out = [ln["alpha"] * x + ln["beta"] * y for x, y in zip(r, e)]
+                    if st["epi"]:
+                        out = vred(weak_norm(out))
+                    res.append((ln["dst"], out))
+                for d, v in res:
+                    self.slot[d] = v
+            elif op == OP_LIN:
+                self.counts["lin_steps"] += 1
+                res = []
+                for dst, terms in st["lanes"]:
+                    acc = [0] * NL
+                    for s, c in terms:
+                        acc = [x + c * y for x, y in zip(acc, self.slot[s])]
+                    res.append((dst, vred(weak_norm(acc))))
+                for d, v in res:
+                    self.slot[d] = v
+            elif op == OP_GLOAD:
+                for dst, idx in st["lanes"]:
+                    if st["kind"] == K_LINE:
+                        pair, c = idx
+                        self.slot[dst] = mont(self.lines[self.cursor][pair][c])
+                    elif st["kind"] == K_STATE:
+                        self.slot[dst] = list(self.state[idx])
+                    else:
+                        v = self.wire_in[idx]
+                        assert 0 <= v < P
+                        self.slot[dst] = [(v >> (W * i)) & ((1 << W) - 1) for i in range(NL)]
+                self.cursor += st.get("advance", 0)
+            elif op == OP_GSTORE:
+                if st["kind"] == K_STATE:
+                    for src, idx in st["lanes"]:
+                        self.state[idx] = list(self.slot[src])
+                else:
+                    out = {}
+                    for src, idx in st["lanes"]:
+                        out[idx] = canonical_from_reduced(self.slot[src])
+                    self.wire_out = [out[i] for i in range(12)]
+                    if st["check"]:
+                        self.is_identity = self.wire_out == [1] + [0] * 11
+            pc += 1
+        return self
+
+
+def model_lines(pairs):
+    """line stream for a check: list over the 68 steps of [per pair (c2, c1*xP, c0*yP)]; pairs with an
+    infinity get the neutral line (1, 0, 0)."""
+    k = len(pairs)
+    rs = [None if (p is None or q is None) else (q[0], q[1], M.F2_ONE) for p, q in pairs]
+    out = []
+
+    def emit(step_fn):
+        row = []
+        for i, (p1, q) in enumerate(pairs):
+            if rs[i] is None:
+                row.append([1, 0, 0, 0, 0, 0])
+                continue
+            rs[i], c = step_fn(i)
+            c0 = M.f2_muls(c[0], p1[1])
+            c1 = M.f2_muls(c[1], p1[0])
+            row.append([c[2][0], c[2][1], c1[0], c1[1], c0[0], c0[1]])
+        out.append(row)
+
+    for has_add in miller_bits():
+        emit(lambda i: M.doubling_step(rs[i]))
+        if has_add:
+            emit(lambda i: M.addition_step(rs[i], pairs[i][1]))
+    emit(lambda i: M.doubling_step(rs[i]))
+    assert len(out) == n_line_steps()
+    return out
+
+
+# ------------------------------------------------------------------------------------------ binary encoding
+def encode(builder):
+    """-> (hdr words, table words).  hdr: 4 words per step: op | arg0<<8 , arg1, table offset, arg2."""
+    hdr, tbl = [], []
+
+    def lanes_pad(lst, filler):
+        return list(lst) + [filler] * (G - len(lst))
+
+    for st in builder.steps:
+        op = st["op"]
+        off = len(tbl)
+        if op == OP_MULACC:
+            T = st["T"]
+            for t in range(T):
+                for ln in lanes_pad(st["lanes"], None):
+                    if ln is None or t >= len(ln["terms"]):
+                        w = ZERO | (ZERO << 7) | (ZERO << 14) | (ZERO << 21)
+                    else:
+                        a1, a2, asub, b1, b2, bsub, neg = ln["terms"][t]
+                        w = a1 | (a2 << 7) | (b1 << 14) | (b2 << 21) | (int(asub) << 28) | (int(bsub) << 29) | (int(neg) << 30)
+                    tbl.append(w)
+            for ln in lanes_pad(st["lanes"], None):
+                if ln is None:
+                    tbl.append(0)
+                else:
+                    assert -8 <= ln["alpha"] <= 7 and -8 <= ln["beta"] <= 7
+                    tbl.append(ln["dst"] | (1 << 7) | ((ln["alpha"] & 15) << 8) | ((ln["beta"] & 15) << 12) | (ln["e"] << 16))
+            hdr += [op | (T << 8), int(st["epi"]), off, 0]
+        elif op == OP_LIN:
+            nt = st["nt"]
+            for t in range(nt):
+                for ln in lanes_pad(st["lanes"], None):
+                    if ln is None or t >= len(ln[1]):
+                        tbl.append(ZERO)
+                    else:
+                        s, c = ln[1][t]
+                        tbl.append(s | ((c & 0xFF) << 8))
+            for ln in lanes_pad(st["lanes"], None):
+                tbl.append(0 if ln is None else (ln[0] | (1 << 7)))
+            hdr += [op | (nt << 8), 0, off, 0]
+        elif op in (OP_GLOAD, OP_GSTORE):
+            for ln in lanes_pad(st["lanes"], None):
+                if ln is None:
+                    tbl.append(0)
+                else:
+                    slot, idx = ln
+                    if st["kind"] == K_LINE:
+                        idx = idx[0] * 6 + idx[1]
+                    tbl.append(slot | (1 << 7) | (idx << 8))
+            arg = st.get("advance", 0) if op == OP_GLOAD else int(st.get("check", False))
+            hdr += [op | (st["kind"] << 8), arg, off, 0]
+        elif op == OP_LOOP:
+            hdr += [op, st["n"], 0, 0]
+        elif op == OP_ENDLOOP:
+            hdr += [op, 0, 0, 0]
+    hdr += [OP_END, 0, 0, 0]
+    return hdr, tbl
+
+
+PROGRAMS = {
+    "miller1_state": lambda: prog_miller(1, False),
+    "miller1_wire": lambda: prog_miller(1, True),
+    "miller2_state": lambda: prog_miller(2, False),
+    "miller2_wire": lambda: prog_miller(2, True),
+    "miller3_state": lambda: prog_miller(3, False),
+    "miller3_wire": lambda: prog_miller(3, True),
+    "miller4_state": lambda: prog_miller(4, False),
+    "miller4_wire": lambda: prog_miller(4, True),
+    "fexp_a_state": lambda: prog_fexp_a(False),
+    "fexp_a_wire": lambda: prog_fexp_a(True),
+    "fexp_c": lambda: prog_fexp_c(True),
+}
+
+
+def write_inc(path):
+    lines = ["// GENERATED by tools/coopgen.py - do not edit.  Step programs of the lane-cooperative kernels.",
+             "#pragma once", "#include <stdint.h>",
+             "#define ZKP_COOP_G %d" % G, "#define ZKP_COOP_NSLOT_MAX %d" % NSLOT,
+             "#define ZKP_COOP_NCONST %d" % N_CONST, "#define ZKP_COOP_ST_SIZE %d" % ST_SIZE,
+             "#define ZKP_COOP_ST_N %d" % ST_N, "#define ZKP_COOP_ST_NINV %d" % ST_NINV,
+             "#define ZKP_COOP_NLINES %d" % n_line_steps(),
+             "#define ZKP_COOP_VRED_C %d" % VRED_C, "#define ZKP_COOP_VRED_SHIFT_IN %d" % VRED_SHIFT_IN,
+             "#define ZKP_COOP_VRED_SHIFT_OUT %d" % VRED_SHIFT_OUT,
+             "#define ZKP_COOP_P_BAL %s" % ", ".join(str(x) for x in P_BAL)]
+    # constants region: Montgomery limbs (balanced), 16 dwords per constant
+    rows = []
+    for name, val in CONSTS:
+        rows.append(mont(val))
+    rows.append(to_limbs_balanced(RMOD * RMOD % P))
+    rows.append([1] + [0] * (NL - 1))
+    lines.append("static const int32_t ZKP_COOP_CONSTS[%d][16] = {" % N_CONST)
+    for r in rows:
+        lines.append("  {" + ", ".join(str(x) for x in r + [0, 0]) + "},")
+    lines.append("};")
+    names = sorted(PROGRAMS)
+    lines.append("enum { " + ", ".join("ZKP_PROG_%s = %d" % (n.upper(), i) for i, n in enumerate(names)) + ", ZKP_PROG_COUNT = %d };" % len(names))
+    meta = []
+    for n in names:
+        b = PROGRAMS[n]()
+        hdr, tbl = encode(b)
+        lines.append("static const uint32_t ZKP_PROG_%s_HDR[%d] = {%s};" % (n.upper(), len(hdr), ",".join(str(x) for x in hdr)))
+        lines.append("static const uint32_t ZKP_PROG_%s_TBL[%d] = {%s};" % (n.upper(), max(1, len(tbl)), ",".join(str(x) for x in tbl) if tbl else "0"))
+        meta.append((n, len(hdr), len(tbl), b.peak))
+    lines.append("struct ZkpProgDesc { const uint32_t* hdr; uint32_t n_hdr; const uint32_t* tbl; uint32_t n_tbl; uint32_t nslot; };")
+    lines.append("static const ZkpProgDesc ZKP_PROGS[ZKP_PROG_COUNT] = {")
+    for n, nh, nt, peak in meta:
+        lines.append("  {ZKP_PROG_%s_HDR, %d, ZKP_PROG_%s_TBL, %d, %d}," % (n.upper(), nh, n.upper(), max(1, nt), peak))
+    lines.append("};")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return meta
+
+
+if __name__ == "__main__":
+    out = os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_coop_prog.inc")
+    for n, nh, nt, peak in write_inc(out):
+        print("%-16s steps=%4d table_words=%6d peak_slots=%d" % (n, nh // 4, nt, peak))
+    print("wrote", out)

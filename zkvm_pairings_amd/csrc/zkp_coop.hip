@@ -1,12 +1,689 @@
-// zkp_coop.hip -- lane-cooperative kernel family (placeholder until the microcoded kernels land:
-// reports "not available", so the dispatcher keeps using the thread family).
+// zkp_coop.hip -- lane-cooperative kernel family (gfx950): the throughput path of the pairing engine.
+//
+// Pipeline for a chunk of checks (each check = k pairs sharing one Fp12 accumulator):
+//   k_prep_lines   one lane per PAIR: walks the G2 point through the 68 doubling/addition steps of
+//                  the optimal-ate loop (ePrint 2010/354 Alg. 26/27), scales every line by P and
+//                  streams (c2, c1*xP, c0*yP) to HBM as 28-bit-limb records (coalesced).
+//   k_coop(prog)   one check per GROUP of 12 lanes (5 groups per wavefront); lane j owns Fp12
+//                  coefficient j; all tower values live in LDS; a table-driven interpreter executes
+//                  the step program generated (and verified on the CPU) by tools/coopgen.py:
+//                    MULACC  sum of <=12 products into 64-bit columns, ONE Montgomery reduction
+//                    LIN     limb-wise linear combination (no carries), weak normalisation
+//                    GLOAD/GSTORE  line stream / per-check state / wire format
+//   k_batch_inv    one lane per check: the single Fp inversion of the final exponentiation.
+// Programs: miller{k}_{state|wire}, fexp_a_{state|wire}, fexp_c (zkp_coop_prog.inc).
+//
+// Reference anchors: Fp12::mul_by_014 src/fp12.rs:99-111, Fp12::square :173-184, Fp12::invert
+// :186-190 (+ src/fp6.rs:291-309, src/fp2.rs:278-296), conjugate :123-125; pairing semantics
+// SURVEY.md S6 (src/pairings.rs is empty upstream).
 #include "zkp_coop.hpp"
 
+#include <cstdio>
+#include <cstring>
+
+#include "zkp_coop_prog.inc"
+#include "zkp_fp28.hpp"
+
+using namespace zkp28;
+
+namespace {
+
+constexpr int GROUPS = 5;              // checks per wavefront
+constexpr int LIG = ZKP_COOP_G;        // 12 lanes per group
+constexpr int NCONST = ZKP_COOP_NCONST;
+constexpr int ST_SIZE = ZKP_COOP_ST_SIZE;
+constexpr int NLINES = ZKP_COOP_NLINES;
+
+enum { OP_END = 0, OP_MULACC = 1, OP_LIN = 2, OP_GLOAD = 3, OP_GSTORE = 4, OP_LOOP = 5, OP_ENDLOOP = 6 };
+enum { K_LINE = 0, K_STATE = 1, K_WIRE = 2 };
+
+__device__ __constant__ const int32_t K_PBAL[NL] = {ZKP_COOP_P_BAL};
+
+struct CoopArgs {
+    const uint32_t* hdr;
+    const uint32_t* tbl;
+    const int4* consts;      // NCONST records of 4 int4
+    const int4* lines;       // [(step * k + pair) * 6 + c][check] records of 4 int4
+    int4* state;             // [elem][check] records of 4 int4
+    const uint64_t* wire_in;  // n_checks x 72
+    uint64_t* wire_out;       // n_checks x 72 (may be null)
+    uint8_t* ok;              // may be null
+    int* all_ok;              // may be null
+    uint32_t n_checks;
+    uint32_t nc;              // record stride (>= n_checks)
+    uint32_t k;
+    uint32_t S;               // LDS plane stride in int4 (>= nslot, >= NCONST)
+};
+
+// ---- LDS access: quad-plane SoA, record = 4 x int4 at off, off+S, off+2S, off+3S
+__device__ __forceinline__ void lds_ld(int32_t* x, const int4* lds, int off, int S) {
+    int4 v0 = lds[off], v1 = lds[off + S], v2 = lds[off + 2 * S], v3 = lds[off + 3 * S];
+    x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w;
+    x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+    x[8] = v2.x; x[9] = v2.y; x[10] = v2.z; x[11] = v2.w;
+    x[12] = v3.x; x[13] = v3.y;
+}
+__device__ __forceinline__ void lds_st(int4* lds, int off, int S, const int32_t* x) {
+    lds[off] = make_int4(x[0], x[1], x[2], x[3]);
+    lds[off + S] = make_int4(x[4], x[5], x[6], x[7]);
+    lds[off + 2 * S] = make_int4(x[8], x[9], x[10], x[11]);
+    lds[off + 3 * S] = make_int4(x[12], x[13], 0, 0);
+}
+
+// value renormalisation (tools/coopgen.py vred): q = round(top / p_top); x -= q p; weak_norm
+__device__ __forceinline__ void vred(int32_t* x) {
+    int32_t q = ((x[NL - 1] >> ZKP_COOP_VRED_SHIFT_IN) * ZKP_COOP_VRED_C + (1 << (ZKP_COOP_VRED_SHIFT_OUT - 1))) >> ZKP_COOP_VRED_SHIFT_OUT;
+#pragma unroll
+    for (int i = 0; i < NL; i++) x[i] -= q * K_PBAL[i];
+    weak_norm(x);
+}
+
+__device__ __forceinline__ int sext4(uint32_t v) { return ((int32_t)(v << 28)) >> 28; }
+__device__ __forceinline__ int sext8(uint32_t v) { return ((int32_t)(v << 24)) >> 24; }
+
+// canonical [0,p) unsigned 28-bit limbs from a reduced value in (-p, 2p) given as balanced limbs
+__device__ __forceinline__ void canon28(uint32_t* f, const int32_t* x) {
+    int32_t u[NL], y[NL], z[NL];
+    int32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int32_t v = x[i] + carry;
+        if (i < NL - 1) { u[i] = v & MASK; carry = v >> W; } else u[i] = v;
+    }
+    carry = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int32_t v = u[i] - K28_P[i] + carry;
+        if (i < NL - 1) { y[i] = v & MASK; carry = v >> W; } else y[i] = v;
+    }
+    carry = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int32_t v = u[i] + K28_P[i] + carry;
+        if (i < NL - 1) { z[i] = v & MASK; carry = v >> W; } else z[i] = v;
+    }
+    bool neg = u[NL - 1] < 0, ge = y[NL - 1] >= 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) f[i] = (uint32_t)(neg ? z[i] : (ge ? y[i] : u[i]));
+}
+
+__global__ void __launch_bounds__(64) k_coop(CoopArgs A) {
+    extern __shared__ int4 lds[];
+    const int lane = threadIdx.x;
+    const int grp = (lane * 43) >> 9;          // lane / 12 for lane < 64
+    const int lig = lane - grp * LIG;          // lanes 60..63: grp 5, lig 0..3 (never store)
+    const bool lane_ok = grp < GROUPS;
+    const uint32_t check = blockIdx.x * GROUPS + grp;
+    const bool active = lane_ok && check < A.n_checks;
+    const int S = (int)A.S;
+    const int cbase = 0;
+    const int gbase = 4 * S + (lane_ok ? grp : GROUPS - 1) * (4 * S + 3);
+
+    for (int i = lane; i < NCONST * 4; i += 64) lds[(i & 3) * S + (i >> 2)] = A.consts[i];
+    __syncthreads();
+
+    const uint32_t* __restrict__ hdr = A.hdr;
+    const uint32_t* __restrict__ tbl = A.tbl;
+    uint32_t cursor = 0;
+    int pc = 0, loop_pc = 0, loop_left = 0;
+    auto slot_off = [&](uint32_t s) -> int { return ((s & 64) ? cbase : gbase) + (int)(s & 63); };
+
+    for (;;) {
+        const uint32_t h0 = __builtin_amdgcn_readfirstlane(hdr[4 * pc]);
+        const uint32_t h1 = __builtin_amdgcn_readfirstlane(hdr[4 * pc + 1]);
+        const uint32_t off = __builtin_amdgcn_readfirstlane(hdr[4 * pc + 2]);
+        const uint32_t op = h0 & 0xff, arg = (h0 >> 8) & 0xff;
+        if (op == OP_END) break;
+        if (op == OP_MULACC) {
+            Acc acc;
+            acc_zero(acc);
+#pragma unroll 1
+            for (uint32_t t = 0; t < arg; t++) {
+                const uint32_t w = tbl[off + t * LIG + lig];
+                int32_t a[NL], b[NL], a2[NL], b2[NL];
+                lds_ld(a, lds, slot_off(w & 127), S);
+                lds_ld(a2, lds, slot_off((w >> 7) & 127), S);
+                lds_ld(b, lds, slot_off((w >> 14) & 127), S);
+                lds_ld(b2, lds, slot_off((w >> 21) & 127), S);
+                const int32_t ma = -(int32_t)((w >> 28) & 1), mb = -(int32_t)((w >> 29) & 1), mn = -(int32_t)((w >> 30) & 1);
+#pragma unroll
+                for (int i = 0; i < NL; i++) {
+                    int32_t av = a[i] + ((a2[i] ^ ma) - ma);
+                    a[i] = (av ^ mn) - mn;
+                    b[i] = b[i] + ((b2[i] ^ mb) - mb);
+                }
+                acc_mul(acc, a, b);
+            }
+            int32_t r[NL];
+            acc_reduce(r, acc);
+            const uint32_t ew = tbl[off + arg * LIG + lig];
+            if (h1 & 1) {  // step-uniform: epilogue dst = alpha r + beta E, renormalised
+                int32_t e[NL];
+                lds_ld(e, lds, slot_off((ew >> 16) & 127), S);
+                const int32_t al = sext4((ew >> 8) & 15), be = sext4((ew >> 12) & 15);
+#pragma unroll
+                for (int i = 0; i < NL; i++) r[i] = al * r[i] + be * e[i];
+                weak_norm(r);
+                vred(r);
+            }
+            if (active && ((ew >> 7) & 1)) lds_st(lds, gbase + (int)(ew & 63), S, r);
+        } else if (op == OP_LIN) {
+            int32_t r[NL];
+#pragma unroll
+            for (int i = 0; i < NL; i++) r[i] = 0;
+#pragma unroll 1
+            for (uint32_t t = 0; t < arg; t++) {
+                const uint32_t w = tbl[off + t * LIG + lig];
+                int32_t x[NL];
+                lds_ld(x, lds, slot_off(w & 127), S);
+                const int32_t c = sext8((w >> 8) & 0xff);
+#pragma unroll
+                for (int i = 0; i < NL; i++) r[i] += c * x[i];
+            }
+            weak_norm(r);
+            vred(r);
+            const uint32_t ew = tbl[off + arg * LIG + lig];
+            if (active && ((ew >> 7) & 1)) lds_st(lds, gbase + (int)(ew & 63), S, r);
+        } else if (op == OP_GLOAD) {
+            const uint32_t w = tbl[off + lig];
+            const uint32_t idx = w >> 8;
+            if (active && ((w >> 7) & 1)) {
+                int32_t x[NL];
+                if (arg == K_WIRE) {
+                    const uint64_t* src = A.wire_in + (size_t)check * 72 + idx * 6;
+                    uint64_t ww[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) ww[i] = src[i];
+#pragma unroll
+                    for (int i = 0; i < NL; i++) {
+                        const int bit = W * i, word = bit >> 6, sh = bit & 63;
+                        uint64_t v = ww[word] >> sh;
+                        if (sh > 64 - W && word + 1 < 6) v |= ww[word + 1] << (64 - sh);
+                        x[i] = (int32_t)(v & (uint64_t)MASK);
+                    }
+                } else {
+                    size_t rec;
+                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + idx) * A.nc + check;
+                    else rec = (size_t)idx * A.nc + check;
+                    const int4* src = (arg == K_LINE ? A.lines : (const int4*)A.state) + rec * 4;
+                    int4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                    x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+                    x[8] = v2.x; x[9] = v2.y; x[10] = v2.z; x[11] = v2.w; x[12] = v3.x; x[13] = v3.y;
+                }
+                lds_st(lds, gbase + (int)(w & 63), S, x);
+            }
+            cursor += h1;
+        } else if (op == OP_GSTORE) {
+            const uint32_t w = tbl[off + lig];
+            const uint32_t idx = w >> 8;
+            const bool part = active && ((w >> 7) & 1);
+            int32_t x[NL];
+            lds_ld(x, lds, gbase + (int)(w & 63), S);
+            if (arg == K_STATE) {
+                if (part) {
+                    int4* dst = A.state + ((size_t)idx * A.nc + check) * 4;
+                    dst[0] = make_int4(x[0], x[1], x[2], x[3]);
+                    dst[1] = make_int4(x[4], x[5], x[6], x[7]);
+                    dst[2] = make_int4(x[8], x[9], x[10], x[11]);
+                    dst[3] = make_int4(x[12], x[13], 0, 0);
+                }
+            } else {
+                uint32_t f[NL];
+                canon28(f, x);
+                if (part && A.wire_out) {
+                    uint64_t o[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int i = 0; i < NL; i++) {
+                        const int bit = W * i, word = bit >> 6, sh = bit & 63;
+                        o[word] |= (uint64_t)f[i] << sh;
+                        if (sh > 64 - W && word + 1 < 6) o[word + 1] |= (uint64_t)f[i] >> (64 - sh);
+                    }
+                    uint64_t* dst = A.wire_out + (size_t)check * 72 + idx * 6;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) dst[i] = o[i];
+                }
+                if (h1 & 1) {  // Gt == identity ?  coefficient 0 must be 1, the others 0
+                    uint32_t d = f[0] ^ (idx == 0 ? 1u : 0u);
+#pragma unroll
+                    for (int i = 1; i < NL; i++) d |= f[i];
+                    const unsigned long long good = __ballot((d == 0) || !part);
+                    const unsigned gm = (unsigned)((good >> (grp * LIG)) & 0xfffu);
+                    if (active && lig == 0) {
+                        const bool is_one = gm == 0xfffu;
+                        if (A.ok) A.ok[check] = is_one ? 1 : 0;
+                        if (A.all_ok && !is_one) atomicAnd(A.all_ok, 0);
+                    }
+                }
+            }
+        } else if (op == OP_LOOP) {
+            loop_pc = pc + 1;
+            loop_left = (int)h1;
+        } else if (op == OP_ENDLOOP) {
+            if (--loop_left > 0) { pc = loop_pc; continue; }
+        }
+        pc++;
+    }
+}
+
+// =============================================================================== thread-level Fp28 helpers
+struct F2 { Fp28 c0, c1; };
+
+__device__ __forceinline__ void f_add(Fp28& r, const Fp28& a, const Fp28& b) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
+    weak_norm(r.l);
+}
+__device__ __forceinline__ void f_sub(Fp28& r, const Fp28& a, const Fp28& b) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] - b.l[i];
+    weak_norm(r.l);
+}
+__device__ __forceinline__ void f_set(Fp28& r, const int32_t* k) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = k[i];
+}
+__device__ __forceinline__ void f_zero(Fp28& r) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = 0;
+}
+__device__ __forceinline__ void f2_add(F2& r, const F2& a, const F2& b) { f_add(r.c0, a.c0, b.c0); f_add(r.c1, a.c1, b.c1); }
+__device__ __forceinline__ void f2_sub(F2& r, const F2& a, const F2& b) { f_sub(r.c0, a.c0, b.c0); f_sub(r.c1, a.c1, b.c1); }
+__device__ __forceinline__ void f2_dbl(F2& r, const F2& a) { f2_add(r, a, a); }
+__device__ __forceinline__ void f2_neg(F2& r, const F2& a) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) { r.c0.l[i] = -a.c0.l[i]; r.c1.l[i] = -a.c1.l[i]; }
+}
+// renormalise the VALUE into (-0.51p, 0.51p); keeps every thread-level operand small
+__device__ __forceinline__ void f2_vred(F2& r) { vred(r.c0.l); vred(r.c1.l); }
+
+// lazy Fp2 product: each output coefficient is two products in one accumulator, one reduction
+__device__ __attribute__((noinline)) void f2_mul(F2* r, const F2* a, const F2* b) {
+    Acc acc;
+    int32_t n[NL];
+    F2 o;
+    acc_zero(acc);
+    acc_mul(acc, a->c0.l, b->c0.l);
+#pragma unroll
+    for (int i = 0; i < NL; i++) n[i] = -a->c1.l[i];
+    acc_mul(acc, n, b->c1.l);
+    acc_reduce(o.c0.l, acc);
+    acc_zero(acc);
+    acc_mul(acc, a->c0.l, b->c1.l);
+    acc_mul(acc, a->c1.l, b->c0.l);
+    acc_reduce(o.c1.l, acc);
+    *r = o;
+}
+__device__ __attribute__((noinline)) void f2_sqr(F2* r, const F2* a) {
+    Acc acc;
+    int32_t s[NL], d[NL];
+    F2 o;
+#pragma unroll
+    for (int i = 0; i < NL; i++) { s[i] = a->c0.l[i] + a->c1.l[i]; d[i] = a->c0.l[i] - a->c1.l[i]; }
+    acc_zero(acc);
+    acc_mul(acc, s, d);
+    acc_reduce(o.c0.l, acc);
+#pragma unroll
+    for (int i = 0; i < NL; i++) s[i] = 2 * a->c0.l[i];
+    acc_zero(acc);
+    acc_mul(acc, s, a->c1.l);
+    acc_reduce(o.c1.l, acc);
+    *r = o;
+}
+__device__ __attribute__((noinline)) void f_mul_ni(Fp28* r, const Fp28* a, const Fp28* b) { fp28_mul(*r, *a, *b); }
+
+__device__ __forceinline__ void rec_store(int4* dst, const Fp28& x) {
+    dst[0] = make_int4(x.l[0], x.l[1], x.l[2], x.l[3]);
+    dst[1] = make_int4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    dst[2] = make_int4(x.l[8], x.l[9], x.l[10], x.l[11]);
+    dst[3] = make_int4(x.l[12], x.l[13], 0, 0);
+}
+__device__ __forceinline__ void rec_load(Fp28& x, const int4* src) {
+    int4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+    x.l[0] = v0.x; x.l[1] = v0.y; x.l[2] = v0.z; x.l[3] = v0.w; x.l[4] = v1.x; x.l[5] = v1.y; x.l[6] = v1.z; x.l[7] = v1.w;
+    x.l[8] = v2.x; x.l[9] = v2.y; x.l[10] = v2.z; x.l[11] = v2.w; x.l[12] = v3.x; x.l[13] = v3.y;
+}
+
+struct G2J { F2 x, y, z; };
+
+// ePrint 2010/354 Alg. 26; returns the line as (c0, c1, c2) and advances r
+__device__ __attribute__((noinline)) void dbl_step(F2* l0, F2* l1, F2* l2, G2J* r) {
+    F2 tmp0, tmp1, tmp2, tmp3, tmp4, tmp5, tmp6, zsq, nx, ny, nz, t;
+    f2_sqr(&tmp0, &r->x);
+    f2_sqr(&tmp1, &r->y);
+    f2_sqr(&tmp2, &tmp1);
+    f2_add(t, tmp1, r->x);
+    f2_sqr(&tmp3, &t);
+    f2_sub(tmp3, tmp3, tmp0);
+    f2_sub(tmp3, tmp3, tmp2);
+    f2_dbl(tmp3, tmp3);
+    f2_add(tmp4, tmp0, tmp0);
+    f2_add(tmp4, tmp4, tmp0);
+    f2_add(tmp6, r->x, tmp4);
+    f2_sqr(&tmp5, &tmp4);
+    f2_sqr(&zsq, &r->z);
+    f2_sub(nx, tmp5, tmp3);
+    f2_sub(nx, nx, tmp3);
+    f2_add(nz, r->z, r->y);
+    f2_sqr(&nz, &nz);
+    f2_sub(nz, nz, tmp1);
+    f2_sub(nz, nz, zsq);
+    f2_sub(ny, tmp3, nx);
+    f2_mul(&ny, &ny, &tmp4);
+    f2_dbl(tmp2, tmp2); f2_dbl(tmp2, tmp2); f2_dbl(tmp2, tmp2);
+    f2_sub(ny, ny, tmp2);
+    f2_mul(&tmp3, &tmp4, &zsq);
+    f2_dbl(tmp3, tmp3);
+    f2_neg(tmp3, tmp3);
+    f2_sqr(&tmp6, &tmp6);
+    f2_sub(tmp6, tmp6, tmp0);
+    f2_sub(tmp6, tmp6, tmp5);
+    f2_dbl(tmp1, tmp1); f2_dbl(tmp1, tmp1);
+    f2_sub(tmp6, tmp6, tmp1);
+    f2_mul(&tmp0, &nz, &zsq);
+    f2_dbl(tmp0, tmp0);
+    f2_vred(nx); f2_vred(ny); f2_vred(nz);
+    r->x = nx; r->y = ny; r->z = nz;
+    *l0 = tmp0; *l1 = tmp3; *l2 = tmp6;
+}
+// ePrint 2010/354 Alg. 27
+__device__ __attribute__((noinline)) void add_step(F2* l0, F2* l1, F2* l2, G2J* r, const F2* qx, const F2* qy) {
+    F2 zsq, ysq, t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, nx, ny, nz, ztsq;
+    f2_sqr(&zsq, &r->z);
+    f2_sqr(&ysq, qy);
+    f2_mul(&t0, &zsq, qx);
+    f2_add(t1, *qy, r->z);
+    f2_sqr(&t1, &t1);
+    f2_sub(t1, t1, ysq);
+    f2_sub(t1, t1, zsq);
+    f2_mul(&t1, &t1, &zsq);
+    f2_sub(t2, t0, r->x);
+    f2_sqr(&t3, &t2);
+    f2_dbl(t4, t3);
+    f2_dbl(t4, t4);
+    f2_mul(&t5, &t4, &t2);
+    f2_sub(t6, t1, r->y);
+    f2_sub(t6, t6, r->y);
+    f2_mul(&t9, &t6, qx);
+    f2_mul(&t7, &t4, &r->x);
+    f2_sqr(&nx, &t6);
+    f2_sub(nx, nx, t5);
+    f2_sub(nx, nx, t7);
+    f2_sub(nx, nx, t7);
+    f2_add(nz, r->z, t2);
+    f2_sqr(&nz, &nz);
+    f2_sub(nz, nz, zsq);
+    f2_sub(nz, nz, t3);
+    f2_add(t10, *qy, nz);
+    f2_sub(t8, t7, nx);
+    f2_mul(&t8, &t8, &t6);
+    f2_mul(&t0, &r->y, &t5);
+    f2_dbl(t0, t0);
+    f2_sub(ny, t8, t0);
+    f2_sqr(&t10, &t10);
+    f2_sub(t10, t10, ysq);
+    f2_sqr(&ztsq, &nz);
+    f2_sub(t10, t10, ztsq);
+    f2_dbl(t9, t9);
+    f2_sub(t9, t9, t10);
+    f2_dbl(t10, nz);
+    f2_neg(t6, t6);
+    f2_dbl(t1, t6);
+    f2_vred(nx); f2_vred(ny); f2_vred(nz);
+    r->x = nx; r->y = ny; r->z = nz;
+    *l0 = t10; *l1 = t1; *l2 = t9;
+}
+
+// one lane per pair: write the 68-step line stream of pair `pid` (check = pid / k, j = pid % k)
+__global__ void __launch_bounds__(64) k_prep_lines(const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
+                                                    uint32_t n_pairs, uint32_t k, uint32_t nc, int4* lines) {
+    const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
+    if (pid >= n_pairs) return;
+    const uint32_t check = pid / k, j = pid - check * k;
+    const bool dead = (inf1 && inf1[pid]) || (inf2 && inf2[pid]);
+    auto rec = [&](uint32_t step, uint32_t c) -> int4* { return lines + ((((size_t)step * k + j) * 6 + c) * nc + check) * 4; };
+    if (dead) {  // neutral line: f * (1 + 0 v + 0 v w) = f
+        Fp28 one, zero;
+        f_set(one, K28_ONE);
+        f_zero(zero);
+        for (uint32_t s = 0; s < (uint32_t)NLINES; s++) {
+            rec_store(rec(s, 0), one);
+            for (uint32_t c = 1; c < 6; c++) rec_store(rec(s, c), zero);
+        }
+        return;
+    }
+    Fp28 px, py;
+    F2 qx, qy;
+    fp28_from_wire(px, g1 + 12 * (size_t)pid);
+    fp28_from_wire(py, g1 + 12 * (size_t)pid + 6);
+    fp28_from_wire(qx.c0, g2 + 24 * (size_t)pid);
+    fp28_from_wire(qx.c1, g2 + 24 * (size_t)pid + 6);
+    fp28_from_wire(qy.c0, g2 + 24 * (size_t)pid + 12);
+    fp28_from_wire(qy.c1, g2 + 24 * (size_t)pid + 18);
+    G2J r;
+    r.x = qx;
+    r.y = qy;
+    f_set(r.z.c0, K28_ONE);
+    f_zero(r.z.c1);
+    uint32_t step = 0;
+    auto emit = [&](F2& l0, F2& l1, F2& l2) {
+        // stream order (c2, c1 * xP, c0 * yP) = the (c0, c1, c4) operands of mul_by_014
+        Fp28 t;
+        vred(l2.c0.l); vred(l2.c1.l);
+        rec_store(rec(step, 0), l2.c0);
+        rec_store(rec(step, 1), l2.c1);
+        f_mul_ni(&t, &l1.c0, &px); rec_store(rec(step, 2), t);
+        f_mul_ni(&t, &l1.c1, &px); rec_store(rec(step, 3), t);
+        f_mul_ni(&t, &l0.c0, &py); rec_store(rec(step, 4), t);
+        f_mul_ni(&t, &l0.c1, &py); rec_store(rec(step, 5), t);
+        step++;
+    };
+    F2 l0, l1, l2;
+    const uint64_t xs = 0xd201000000010000ULL >> 1;
+    bool found = false;
+    for (int b = 63; b >= 0; b--) {
+        const bool bit = (xs >> b) & 1;
+        if (!found) { found = bit; continue; }
+        dbl_step(&l0, &l1, &l2, &r);
+        emit(l0, l1, l2);
+        if (bit) {
+            add_step(&l0, &l1, &l2, &r, &qx, &qy);
+            emit(l0, l1, l2);
+        }
+    }
+    dbl_step(&l0, &l1, &l2, &r);
+    emit(l0, l1, l2);
+}
+
+// one lane per check: state[ST_NINV] = state[ST_N]^-1 (Fermat, a^(p-2); reference src/fp.rs:307-319)
+__global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks, uint32_t nc) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_checks) return;
+    Fp28 a, res;
+    rec_load(a, state + ((size_t)ZKP_COOP_ST_N * nc + i) * 4);
+    f_set(res, K28_ONE);
+    // p - 2 in 28-bit limbs: p's limbs with 2 subtracted from limb 0 (no borrow: limb 0 = 0xfffaaab)
+    for (int w = NL - 1; w >= 0; w--) {
+        uint32_t e = (uint32_t)K28_P[w] - (w == 0 ? 2u : 0u);
+        for (int b = W - 1; b >= 0; b--) {
+            f_mul_ni(&res, &res, &res);
+            if ((e >> b) & 1) f_mul_ni(&res, &res, &a);
+        }
+    }
+    rec_store(state + ((size_t)ZKP_COOP_ST_NINV * nc + i) * 4, res);
+}
+
+// fp28 multiply on wire operands (test hook for the 28-bit core)
+__global__ void k_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp28 x, y, r;
+    fp28_from_wire(x, a + 6 * i);
+    fp28_from_wire(y, b + 6 * i);
+    fp28_mul(r, x, y);
+    fp28_to_wire(out + 6 * i, r);
+}
+
+}  // namespace
+
+// =============================================================================== host side
 namespace zkp {
-hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) { st->available = false; st->cus = prop.multiProcessorCount; return hipSuccess; }
-void coop_free(CoopState*) {}
-bool coop_selected(const CoopState* st, int kind) { return st->available && kind != 1; }
-hipError_t coop_miller(CoopState*, const uint64_t*, const uint64_t*, const uint8_t*, const uint8_t*, size_t, size_t, uint64_t*, hipStream_t) { return hipErrorNotSupported; }
-hipError_t coop_final_exp(CoopState*, const uint64_t*, size_t, uint64_t*, hipStream_t) { return hipErrorNotSupported; }
-hipError_t coop_pairing(CoopState*, const uint64_t*, const uint64_t*, const uint8_t*, const uint8_t*, size_t, size_t, uint64_t*, uint8_t*, int*, hipStream_t) { return hipErrorNotSupported; }
+
+struct CoopProgDev { uint32_t* hdr; uint32_t* tbl; uint32_t nslot; };
+struct CoopDev {
+    CoopProgDev progs[ZKP_PROG_COUNT];
+    int4* consts;
+    int4* lines;  size_t lines_bytes;
+    int4* state;  size_t state_bytes;
+};
+
+static const size_t CHUNK = 1 << 16;   // checks per pipeline pass (bounds the line-stream workspace)
+
+hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
+    st->cus = prop.multiProcessorCount;
+    CoopDev* d = new CoopDev();
+    memset(d, 0, sizeof(*d));
+    hipError_t e;
+    for (int i = 0; i < ZKP_PROG_COUNT; i++) {
+        const ZkpProgDesc& p = ZKP_PROGS[i];
+        if ((e = hipMalloc((void**)&d->progs[i].hdr, p.n_hdr * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&d->progs[i].tbl, p.n_tbl * 4)) != hipSuccess) return e;
+        if ((e = hipMemcpy(d->progs[i].hdr, p.hdr, p.n_hdr * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        if ((e = hipMemcpy(d->progs[i].tbl, p.tbl, p.n_tbl * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        d->progs[i].nslot = p.nslot;
+    }
+    if ((e = hipMalloc((void**)&d->consts, sizeof(ZKP_COOP_CONSTS))) != hipSuccess) return e;
+    if ((e = hipMemcpy(d->consts, ZKP_COOP_CONSTS, sizeof(ZKP_COOP_CONSTS), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    st->d_prog = d;
+    st->available = true;
+    return hipSuccess;
+}
+
+void coop_free(CoopState* st) {
+    CoopDev* d = (CoopDev*)st->d_prog;
+    if (!d) return;
+    for (int i = 0; i < ZKP_PROG_COUNT; i++) {
+        if (d->progs[i].hdr) (void)hipFree(d->progs[i].hdr);
+        if (d->progs[i].tbl) (void)hipFree(d->progs[i].tbl);
+    }
+    if (d->consts) (void)hipFree(d->consts);
+    if (d->lines) (void)hipFree(d->lines);
+    if (d->state) (void)hipFree(d->state);
+    delete d;
+    st->d_prog = nullptr;
+    st->available = false;
+}
+
+// AUTO (0) keeps the thread family until ZKP_KERNEL=coop / zkp_set_kernel(COOP) asks for this one
+bool coop_selected(const CoopState* st, int kind) { return st->available && kind == 2; }
+
+static hipError_t ensure_buf(int4** p, size_t* cap, size_t bytes) {
+    if (bytes <= *cap) return hipSuccess;
+    if (*p) { hipError_t e = hipFree(*p); if (e != hipSuccess) return e; *p = nullptr; *cap = 0; }
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e == hipSuccess) *cap = bytes;
+    return e;
+}
+
+static hipError_t run_prog(CoopDev* d, int prog, uint32_t n_checks, uint32_t nc, uint32_t k, const uint64_t* wire_in, uint64_t* wire_out,
+                           uint8_t* ok, int* all_ok, hipStream_t s) {
+    CoopArgs a;
+    a.hdr = d->progs[prog].hdr;
+    a.tbl = d->progs[prog].tbl;
+    a.consts = d->consts;
+    a.lines = d->lines;
+    a.state = d->state;
+    a.wire_in = wire_in;
+    a.wire_out = wire_out;
+    a.ok = ok;
+    a.all_ok = all_ok;
+    a.n_checks = n_checks;
+    a.nc = nc;
+    a.k = k;
+    uint32_t S = d->progs[prog].nslot > (uint32_t)NCONST ? d->progs[prog].nslot : (uint32_t)NCONST;
+    a.S = S;
+    size_t lds_bytes = (size_t)(4 * S + GROUPS * (4 * S + 3)) * 16;
+    unsigned blocks = (n_checks + GROUPS - 1) / GROUPS;
+    hipLaunchKernelGGL(k_coop, dim3(blocks), dim3(64), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+static int miller_prog(size_t k, bool wire) {
+    switch (k) {
+        case 1: return wire ? ZKP_PROG_MILLER1_WIRE : ZKP_PROG_MILLER1_STATE;
+        case 2: return wire ? ZKP_PROG_MILLER2_WIRE : ZKP_PROG_MILLER2_STATE;
+        case 3: return wire ? ZKP_PROG_MILLER3_WIRE : ZKP_PROG_MILLER3_STATE;
+        case 4: return wire ? ZKP_PROG_MILLER4_WIRE : ZKP_PROG_MILLER4_STATE;
+        default: return -1;
+    }
+}
+
+bool coop_supports_k(size_t k) { return k >= 1 && k <= 4; }
+
+static hipError_t prep(CoopDev* d, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t base_check, uint32_t n,
+                       uint32_t k, hipStream_t s) {
+    hipError_t e = ensure_buf(&d->lines, &d->lines_bytes, (size_t)NLINES * k * 6 * n * 64);
+    if (e != hipSuccess) return e;
+    size_t p0 = base_check * k;
+    uint32_t n_pairs = n * k;
+    hipLaunchKernelGGL(k_prep_lines, dim3((n_pairs + 63) / 64), dim3(64), 0, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
+                       i2 ? i2 + p0 : nullptr, n_pairs, k, n, d->lines);
+    return hipGetLastError();
+}
+
+hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
+                       uint64_t* out, hipStream_t s) {
+    CoopDev* d = (CoopDev*)st->d_prog;
+    int prog = miller_prog(k, true);
+    if (prog < 0) return hipErrorNotSupported;
+    for (size_t base = 0; base < n_checks; base += CHUNK) {
+        uint32_t n = (uint32_t)((n_checks - base) < CHUNK ? (n_checks - base) : CHUNK);
+        hipError_t e = prep(d, g1, g2, i1, i2, base, n, (uint32_t)k, s);
+        if (e != hipSuccess) return e;
+        if ((e = run_prog(d, prog, n, n, (uint32_t)k, nullptr, out + 72 * base, nullptr, nullptr, s)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static hipError_t fexp_tail(CoopDev* d, uint32_t n, uint64_t* out, uint8_t* ok, int* all_ok, hipStream_t s) {
+    hipLaunchKernelGGL(k_batch_inv, dim3((n + 63) / 64), dim3(64), 0, s, d->state, n, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return run_prog(d, ZKP_PROG_FEXP_C, n, n, 1, nullptr, out, ok, all_ok, s);
+}
+
+hipError_t coop_final_exp(CoopState* st, const uint64_t* f, size_t n_total, uint64_t* out, hipStream_t s) {
+    CoopDev* d = (CoopDev*)st->d_prog;
+    for (size_t base = 0; base < n_total; base += CHUNK) {
+        uint32_t n = (uint32_t)((n_total - base) < CHUNK ? (n_total - base) : CHUNK);
+        hipError_t e = ensure_buf(&d->state, &d->state_bytes, (size_t)ST_SIZE * n * 64);
+        if (e != hipSuccess) return e;
+        if ((e = run_prog(d, ZKP_PROG_FEXP_A_WIRE, n, n, 1, f + 72 * base, nullptr, nullptr, nullptr, s)) != hipSuccess) return e;
+        if ((e = fexp_tail(d, n, out + 72 * base, nullptr, nullptr, s)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
+                        uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s) {
+    CoopDev* d = (CoopDev*)st->d_prog;
+    int prog = miller_prog(k, false);
+    if (prog < 0) return hipErrorNotSupported;
+    for (size_t base = 0; base < n_checks; base += CHUNK) {
+        uint32_t n = (uint32_t)((n_checks - base) < CHUNK ? (n_checks - base) : CHUNK);
+        hipError_t e = ensure_buf(&d->state, &d->state_bytes, (size_t)ST_SIZE * n * 64);
+        if (e != hipSuccess) return e;
+        if ((e = prep(d, g1, g2, i1, i2, base, n, (uint32_t)k, s)) != hipSuccess) return e;
+        if ((e = run_prog(d, prog, n, n, (uint32_t)k, nullptr, nullptr, nullptr, nullptr, s)) != hipSuccess) return e;
+        if ((e = run_prog(d, ZKP_PROG_FEXP_A_STATE, n, n, 1, nullptr, nullptr, nullptr, nullptr, s)) != hipSuccess) return e;
+        if ((e = fexp_tail(d, n, out_gt ? out_gt + 72 * base : nullptr, ok ? ok + base : nullptr, all_ok, s)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t coop_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_fp28_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, n, out);
+    return hipGetLastError();
+}
+
 }  // namespace zkp

@@ -19,6 +19,10 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop);
 void coop_free(CoopState* st);
 // true when `kind` (zkp_kernel_kind) routes the pairing path through the cooperative kernels
 bool coop_selected(const CoopState* st, int kind);
+// lane-cooperative programs exist for 1..4 pairs per check; other k use the thread family
+bool coop_supports_k(size_t k);
+// test hook: 28-bit-limb Montgomery multiply on wire operands
+hipError_t coop_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, hipStream_t s);
 hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks,
                        size_t k, uint64_t* out, hipStream_t s);
 hipError_t coop_final_exp(CoopState* st, const uint64_t* f, size_t n, uint64_t* out, hipStream_t s);

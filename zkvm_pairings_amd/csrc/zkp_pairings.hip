@@ -274,7 +274,7 @@ int bind(zkp_ctx* c) {
 int miller_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
                uint64_t* out, hipStream_t s) {
     if (n_checks == 0) return ZKP_OK;
-    if (zkp::coop_selected(&c->coop, c->kernel))
+    if (zkp::coop_selected(&c->coop, c->kernel) && zkp::coop_supports_k(k))
         return zkp::coop_miller(&c->coop, g1, g2, i1, i2, n_checks, k, out, s) == hipSuccess ? ZKP_OK : (c->err = "coop_miller launch failed", ZKP_ERR_HIP);
     hipLaunchKernelGGL(k_miller, dim3(grid_for(n_checks, TPB)), dim3(TPB), 0, s, g1, g2, i1, i2, n_checks, k, out);
     HIPCHK(c, hipGetLastError());
@@ -295,7 +295,7 @@ int pairing_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_
         HIPCHK(c, hipGetLastError());
     }
     if (n_checks == 0) return ZKP_OK;
-    if (zkp::coop_selected(&c->coop, c->kernel))
+    if (zkp::coop_selected(&c->coop, c->kernel) && zkp::coop_supports_k(k))
         return zkp::coop_pairing(&c->coop, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok, s) == hipSuccess ? ZKP_OK : (c->err = "coop_pairing launch failed", ZKP_ERR_HIP);
     hipLaunchKernelGGL(k_pairing, dim3(grid_for(n_checks, TPB)), dim3(TPB), 0, s, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok);
     HIPCHK(c, hipGetLastError());
@@ -600,7 +600,7 @@ int zkp_g2_mul_batch(zkp_ctx* c, const uint64_t* base, size_t stride, const uint
     return mul_host(c, 2, base, stride, sc, n, out, out_inf);
 }
 int zkp_fp_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
-    if (!c || (op != 0 && op != 1) || (n && (!a || !b || !out))) return ZKP_ERR_ARG;
+    if (!c || (op != 0 && op != 1 && op != 2) || (n && (!a || !b || !out))) return ZKP_ERR_ARG;
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
@@ -608,8 +608,12 @@ int zkp_fp_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, si
     HIPCHK(c, hipMemcpyAsync(c->buf[0], a, n * 48, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->buf[1], b, n * 48, hipMemcpyHostToDevice, c->stream));
     if ((rc = validate_dev(c, (const uint64_t*)c->buf[0], n)) || (rc = validate_dev(c, (const uint64_t*)c->buf[1], n))) return rc;
-    hipLaunchKernelGGL(k_fp_op, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, op, (const uint64_t*)c->buf[0], (const uint64_t*)c->buf[1], n, (uint64_t*)c->buf[4]);
-    HIPCHK(c, hipGetLastError());
+    if (op == 2) {  // same product through the 28-bit carry-free core of the cooperative family
+        HIPCHK(c, zkp::coop_fp28_mul((const uint64_t*)c->buf[0], (const uint64_t*)c->buf[1], n, (uint64_t*)c->buf[4], c->stream));
+    } else {
+        hipLaunchKernelGGL(k_fp_op, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, op, (const uint64_t*)c->buf[0], (const uint64_t*)c->buf[1], n, (uint64_t*)c->buf[4]);
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipMemcpyAsync(out, c->buf[4], n * 48, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ZKP_OK;
