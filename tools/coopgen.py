@@ -422,9 +422,8 @@ class Builder:
         Tt = tuple(lin2(ts[6 + 2 * j], ts[6 + 2 * j + 1]) for j in range(3))
         ab = b6_mul(a0, a1)
         st = b6_mul(S, Tt)
-        tmp = self.alloc(12)
+        tmp = ts   # in place: every lane finishes reading S, T before any lane stores its product
         self.mulacc([{"dst": tmp[i], "bil": bl} for i, bl in enumerate(flatten12(ab, st))])
-        self.release(ts)
         AB = tuple(lin2(tmp[2 * j], tmp[2 * j + 1]) for j in range(3))
         ST = tuple(lin2(tmp[6 + 2 * j], tmp[6 + 2 * j + 1]) for j in range(3))
         vab = l6_mul_v(AB)
@@ -699,41 +698,44 @@ def prog_fexp_c(to_wire=True):
     t2 = b.frobenius(f, u, 2)
     t2 = b.fp12_mul(t2, t2, u)
     # hard part: the upstream-shaped x-chain of DESIGN.md / SURVEY.md S6 (the products of the last
-    # lines are associated differently to bound LDS residency; exact field arithmetic => same value)
+    # lines are associated differently to bound LDS residency; exact field arithmetic => same value).
+    # At most three Fp12 values are LDS-resident at any time.
     t1 = b.cyclotomic_sqr(u, t2).conj()
-    t3 = cyc_exp(b, t2)
-    t4 = b.cyclotomic_sqr(b.alloc(12), t3)
-    t5 = b.fp12_mul(t1, t1, t3)                 # t1's slots now hold t5
-    h4 = b.spill(t4, ST_SPILL + 0)
-    h3 = b.spill(t3, ST_SPILL + 12)
-    t1 = cyc_exp(b, t5)
-    h5 = b.spill(t5, ST_SPILL + 24)
-    t0 = cyc_exp(b, t1)
-    h1 = b.spill(t1, ST_SPILL + 36)
+    t3 = cyc_exp(b, t2)                          # resident: t1 t2 t3
     h2 = b.spill(t2, ST_SPILL + 48)
-    t6 = cyc_exp(b, t0)
+    t4 = b.cyclotomic_sqr(b.alloc(12), t3)       # t1 t3 t4
+    h4 = b.spill(t4, ST_SPILL + 0)
+    t5 = b.fp12_mul(t1, t1, t3)                  # t1's slots now hold t5 ; t3 t5
+    h3 = b.spill(t3, ST_SPILL + 12)
+    t1 = cyc_exp(b, t5)                          # t5 t1
+    h5 = b.spill(t5, ST_SPILL + 24)
+    t0 = cyc_exp(b, t1)                          # t1 t0
+    h1 = b.spill(t1, ST_SPILL + 36)
+    t6 = cyc_exp(b, t0)                          # t0 t6
     h0 = b.spill(t0, ST_SPILL + 60)
     t4 = b.fill(h4)
     t6 = b.fp12_mul(t6, t6, t4)
     b.release(t4.slots)
-    t4 = cyc_exp(b, t6)
-    t2 = b.fill(h2)
-    t5 = b.fill(h5)
+    t4 = cyc_exp(b, t6)                          # t6 t4
+    t2 = b.fill(h2)                              # t6 t4 t2
+    t6 = b.fp12_mul(t6, t6, t2.conj())
+    t6 = b.frobenius(t6, t6, 1)
+    h6 = b.spill(t6, ST_SPILL + 0)               # t4 t2
+    t5 = b.fill(h5)                              # t4 t2 t5
     t5 = b.fp12_mul(t5, t5.conj(), t2)
     t4 = b.fp12_mul(t4, t4, t5)
     b.release(t5.slots)
-    t6 = b.fp12_mul(t6, t6, t2.conj())
-    t6 = b.frobenius(t6, t6, 1)
-    t1 = b.fill(h1)
+    t1 = b.fill(h1)                              # t4 t2 t1
     t1 = b.fp12_mul(t1, t1, t2)
     b.release(t2.slots)
     t1 = b.frobenius(t1, t1, 3)
+    t1 = b.fp12_mul(t1, t1, t4)
+    b.release(t4.slots)                          # t1
+    t6 = b.fill(h6)
     t1 = b.fp12_mul(t1, t1, t6)
     b.release(t6.slots)
-    t1 = b.fp12_mul(t1, t1, t4)
-    b.release(t4.slots)
     t3 = b.fill(h3)
-    t0 = b.fill(h0)
+    t0 = b.fill(h0)                              # t1 t3 t0
     t3 = b.fp12_mul(t3, t3, t0)
     b.release(t0.slots)
     t3 = b.frobenius(t3, t3, 2)
@@ -991,7 +993,14 @@ def encode(builder):
                 else:
                     assert -8 <= ln["alpha"] <= 7 and -8 <= ln["beta"] <= 7
                     tbl.append(ln["dst"] | (1 << 7) | ((ln["alpha"] & 15) << 8) | ((ln["beta"] & 15) << 12) | (ln["e"] << 16))
-            hdr += [op | (T << 8), int(st["epi"]), off, 0]
+            no_a2 = no_b2 = 0
+            for t in range(T):
+                ts_ = [ln["terms"][t] for ln in st["lanes"] if t < len(ln["terms"])]
+                if all(x[1] == ZERO and not x[2] for x in ts_):
+                    no_a2 |= 1 << t
+                if all(x[4] == ZERO and not x[5] for x in ts_):
+                    no_b2 |= 1 << t
+            hdr += [op | (T << 8), int(st["epi"]), off, no_a2 | (no_b2 << 12)]
         elif op == OP_LIN:
             nt = st["nt"]
             for t in range(nt):

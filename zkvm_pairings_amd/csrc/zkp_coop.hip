@@ -52,7 +52,7 @@ struct CoopArgs {
     uint32_t n_checks;
     uint32_t nc;              // record stride (>= n_checks)
     uint32_t k;
-    uint32_t S;               // LDS plane stride in int4 (>= nslot, >= NCONST)
+    uint32_t S;               // LDS plane stride (int4) of a group region (= the program's slot count)
 };
 
 // ---- LDS access: quad-plane SoA, record = 4 x int4 at off, off+S, off+2S, off+3S
@@ -116,10 +116,11 @@ __global__ void __launch_bounds__(64) k_coop(CoopArgs A) {
     const uint32_t check = blockIdx.x * GROUPS + grp;
     const bool active = lane_ok && check < A.n_checks;
     const int S = (int)A.S;
+    constexpr int SC = NCONST;                 // plane stride of the constants region
     const int cbase = 0;
-    const int gbase = 4 * S + (lane_ok ? grp : GROUPS - 1) * (4 * S + 3);
+    const int gbase = 4 * SC + (lane_ok ? grp : GROUPS - 1) * (4 * S + 3);
 
-    for (int i = lane; i < NCONST * 4; i += 64) lds[(i & 3) * S + (i >> 2)] = A.consts[i];
+    for (int i = lane; i < NCONST * 4; i += 64) lds[(i & 3) * SC + (i >> 2)] = A.consts[i];
     __syncthreads();
 
     const uint32_t* __restrict__ hdr = A.hdr;
@@ -127,6 +128,7 @@ __global__ void __launch_bounds__(64) k_coop(CoopArgs A) {
     uint32_t cursor = 0;
     int pc = 0, loop_pc = 0, loop_left = 0;
     auto slot_off = [&](uint32_t s) -> int { return ((s & 64) ? cbase : gbase) + (int)(s & 63); };
+    auto ld = [&](int32_t* x, uint32_t s) { lds_ld(x, lds, slot_off(s), (s & 64) ? SC : S); };
 
     for (;;) {
         const uint32_t h0 = __builtin_amdgcn_readfirstlane(hdr[4 * pc]);
@@ -135,31 +137,54 @@ __global__ void __launch_bounds__(64) k_coop(CoopArgs A) {
         const uint32_t op = h0 & 0xff, arg = (h0 >> 8) & 0xff;
         if (op == OP_END) break;
         if (op == OP_MULACC) {
+            // software pipeline: table words two terms ahead, LDS operands one term ahead, so the
+            // 196 multiply-adds of term t cover the latency of everything term t+1 needs
+            const uint32_t h3 = __builtin_amdgcn_readfirstlane(hdr[4 * pc + 3]);
+            const uint32_t T = arg;
             Acc acc;
             acc_zero(acc);
+            uint32_t w = tbl[off + lig];
+            uint32_t wn = T > 1 ? tbl[off + LIG + lig] : 0;
+            const uint32_t ew = tbl[off + T * LIG + lig];
+            int32_t xa[NL], xa2[NL], xb[NL], xb2[NL];
+            ld(xa, w & 127);
+            if (!(h3 & 1)) ld(xa2, (w >> 7) & 127);
+            ld(xb, (w >> 14) & 127);
+            if (!((h3 >> 12) & 1)) ld(xb2, (w >> 21) & 127);
 #pragma unroll 1
-            for (uint32_t t = 0; t < arg; t++) {
-                const uint32_t w = tbl[off + t * LIG + lig];
-                int32_t a[NL], b[NL], a2[NL], b2[NL];
-                lds_ld(a, lds, slot_off(w & 127), S);
-                lds_ld(a2, lds, slot_off((w >> 7) & 127), S);
-                lds_ld(b, lds, slot_off((w >> 14) & 127), S);
-                lds_ld(b2, lds, slot_off((w >> 21) & 127), S);
+            for (uint32_t t = 0; t < T; t++) {
+                const bool no_a2 = (h3 >> t) & 1, no_b2 = (h3 >> (12 + t)) & 1;   // wave-uniform
                 const int32_t ma = -(int32_t)((w >> 28) & 1), mb = -(int32_t)((w >> 29) & 1), mn = -(int32_t)((w >> 30) & 1);
+                int32_t a[NL], b[NL];
+                if (no_a2) {
 #pragma unroll
-                for (int i = 0; i < NL; i++) {
-                    int32_t av = a[i] + ((a2[i] ^ ma) - ma);
-                    a[i] = (av ^ mn) - mn;
-                    b[i] = b[i] + ((b2[i] ^ mb) - mb);
+                    for (int i = 0; i < NL; i++) a[i] = (xa[i] ^ mn) - mn;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NL; i++) a[i] = ((xa[i] + ((xa2[i] ^ ma) - ma)) ^ mn) - mn;
+                }
+                if (no_b2) {
+#pragma unroll
+                    for (int i = 0; i < NL; i++) b[i] = xb[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NL; i++) b[i] = xb[i] + ((xb2[i] ^ mb) - mb);
+                }
+                if (t + 1 < T) {
+                    w = wn;
+                    if (t + 2 < T) wn = tbl[off + (t + 2) * LIG + lig];
+                    ld(xa, w & 127);
+                    if (!((h3 >> (t + 1)) & 1)) ld(xa2, (w >> 7) & 127);
+                    ld(xb, (w >> 14) & 127);
+                    if (!((h3 >> (13 + t)) & 1)) ld(xb2, (w >> 21) & 127);
                 }
                 acc_mul(acc, a, b);
             }
             int32_t r[NL];
             acc_reduce(r, acc);
-            const uint32_t ew = tbl[off + arg * LIG + lig];
             if (h1 & 1) {  // step-uniform: epilogue dst = alpha r + beta E, renormalised
                 int32_t e[NL];
-                lds_ld(e, lds, slot_off((ew >> 16) & 127), S);
+                ld(e, (ew >> 16) & 127);
                 const int32_t al = sext4((ew >> 8) & 15), be = sext4((ew >> 12) & 15);
 #pragma unroll
                 for (int i = 0; i < NL; i++) r[i] = al * r[i] + be * e[i];
@@ -175,7 +200,7 @@ __global__ void __launch_bounds__(64) k_coop(CoopArgs A) {
             for (uint32_t t = 0; t < arg; t++) {
                 const uint32_t w = tbl[off + t * LIG + lig];
                 int32_t x[NL];
-                lds_ld(x, lds, slot_off(w & 127), S);
+                ld(x, w & 127);
                 const int32_t c = sext8((w >> 8) & 0xff);
 #pragma unroll
                 for (int i = 0; i < NL; i++) r[i] += c * x[i];
@@ -536,7 +561,7 @@ struct CoopDev {
     int4* state;  size_t state_bytes;
 };
 
-static const size_t CHUNK = 1 << 16;   // checks per pipeline pass (bounds the line-stream workspace)
+static const size_t CHUNK = 1 << 17;   // checks per pipeline pass (bounds the line-stream workspace: 26 KB per pair)
 
 hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     st->cus = prop.multiProcessorCount;
@@ -573,8 +598,8 @@ void coop_free(CoopState* st) {
     st->available = false;
 }
 
-// AUTO (0) keeps the thread family until ZKP_KERNEL=coop / zkp_set_kernel(COOP) asks for this one
-bool coop_selected(const CoopState* st, int kind) { return st->available && kind == 2; }
+// AUTO (0) and COOP (2) route through this family; THREAD (1) forces the one-pairing-per-lane kernels
+bool coop_selected(const CoopState* st, int kind) { return st->available && kind != 1; }
 
 static hipError_t ensure_buf(int4** p, size_t* cap, size_t bytes) {
     if (bytes <= *cap) return hipSuccess;
@@ -599,9 +624,9 @@ static hipError_t run_prog(CoopDev* d, int prog, uint32_t n_checks, uint32_t nc,
     a.n_checks = n_checks;
     a.nc = nc;
     a.k = k;
-    uint32_t S = d->progs[prog].nslot > (uint32_t)NCONST ? d->progs[prog].nslot : (uint32_t)NCONST;
+    uint32_t S = d->progs[prog].nslot;
     a.S = S;
-    size_t lds_bytes = (size_t)(4 * S + GROUPS * (4 * S + 3)) * 16;
+    size_t lds_bytes = (size_t)(4 * NCONST + GROUPS * (4 * S + 3)) * 16;
     unsigned blocks = (n_checks + GROUPS - 1) / GROUPS;
     hipLaunchKernelGGL(k_coop, dim3(blocks), dim3(64), lds_bytes, s, a);
     return hipGetLastError();
