@@ -39,6 +39,7 @@ def main():
     import torch
     import torch.distributed as dist
     import zkvm_pairings_amd as z
+    from zkvm_pairings_amd import dist as zdist
     from zkvm_pairings_amd import synthetic
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,8 +64,7 @@ def main():
 
     def step():
         eng.pairing_gt_check(g1, g2, 1, out_gt, ok, flag)
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # AND of {0,1} flags; RCCL has no bitwise AND
+        zdist.and_reduce(flag)  # AND of {0,1} flags == MIN; the only collective on the path
 
     for _ in range(args.warmup):
         step()
@@ -78,10 +78,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = zdist.max_over_ranks(dt, dev)
     all_ok = int(flag.item())
 
     # dominant-kernel duration: HIP events recorded on the stream the kernel is launched on

@@ -1,0 +1,62 @@
+"""world_size-2 gloo test of the N>1 path (no GPU): contiguous sharding + the single MIN all-reduce
+that implements the cross-GPU AND of the Gt==identity flags."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, ws, port, bad_check, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from zkvm_pairings_amd import dist as zd
+    n = 1001
+    seen = []
+
+    def check_fn(lo, hi):
+        seen.append((lo, hi))
+        ok = 0 if (bad_check is not None and lo <= bad_check < hi) else 1
+        return torch.tensor([ok], dtype=torch.int32)
+
+    res = zd.sharded_pairing_check(check_fn, n, torch.device("cpu"))
+    t = zd.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    q.put((rank, seen[0], res, t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad_check", [None, 3, 1000])
+def test_sharded_and_reduce_gloo(bad_check):
+    ws = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + (0 if bad_check is None else bad_check % 7 + 1)
+    procs = [ctx.Process(target=_worker, args=(r, ws, port, bad_check, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(ws))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, res0, t0), (r1, s1, res1, t1) = out
+    assert s0 == (0, 501) and s1 == (501, 1001)            # contiguous, sizes differ by at most one
+    assert res0 == res1 == (bad_check is None)              # AND over ranks == MIN of {0,1}
+    assert t0 == t1 == 2.0                                  # max over ranks
+
+
+def test_shard_range_partitions():
+    from zkvm_pairings_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 1 << 20, (1 << 20) + 5):
+        for ws in (1, 2, 3, 8):
+            blocks = [shard_range(n, r, ws) for r in range(ws)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(ws - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1

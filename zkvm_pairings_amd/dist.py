@@ -1,0 +1,48 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in
+the CPU tests).  The pairing path shards embarrassingly - every pairing / k-pair check is
+independent - so the batch is split into contiguous blocks per rank and the ONLY
+collective is one all-reduce of the per-rank AND flag.  RCCL has no bitwise-AND reduction, so the
+AND of {0,1} flags is MIN.  Bulk data never crosses xGMI."""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n_total, rank, world_size):
+    """contiguous block [lo, hi) of rank: element i of n_total goes to rank floor(i * world / n_total)-ish,
+    block sizes differ by at most one"""
+    base, rem = divmod(n_total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def and_reduce(flag):
+    """flag: int32 tensor of shape (1,) holding 0/1 on this rank's device -> global AND, in place"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return flag
+
+
+def max_over_ranks(seconds, device):
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sharded_pairing_check(check_fn, n_checks, device):
+    """check_fn(lo, hi) -> int32 tensor (1,) with the AND over this rank's checks [lo, hi).
+    Returns the global AND as a python bool on every rank."""
+    rank, ws = world()
+    lo, hi = shard_range(n_checks, rank, ws)
+    if hi > lo:
+        flag = check_fn(lo, hi)
+    else:
+        flag = torch.ones(1, dtype=torch.int32, device=device)
+    and_reduce(flag)
+    return bool(flag.item())
