@@ -1,7 +1,7 @@
 // zkp_coop.hip -- lane-cooperative kernel family (gfx950): the throughput path of the pairing engine.
 //
 // Pipeline for a chunk of checks (each check = k pairs sharing one Fp12 accumulator):
-//   k_prep_lines   one lane per PAIR: walks the G2 point through the 68 doubling/addition steps of
+//   k_prep_lines   two lanes per PAIR (one per Fp2 coefficient): walks the G2 point through the 68 doubling/addition steps of
 //                  the optimal-ate loop (ePrint 2010/354 Alg. 26/27), scales every line by P and
 //                  streams (c2, c1*xP, c0*yP) to HBM as 28-bit-limb records (coalesced).
 //   k_coop(prog)   one check per GROUP of 12 lanes (5 groups per wavefront); lane j owns Fp12
@@ -291,8 +291,6 @@ __global__ void __launch_bounds__(64) k_coop(CoopArgs A) {
 }
 
 // =============================================================================== thread-level Fp28 helpers
-struct F2 { Fp28 c0, c1; };
-
 __device__ __forceinline__ void f_add(Fp28& r, const Fp28& a, const Fp28& b) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
@@ -311,49 +309,6 @@ __device__ __forceinline__ void f_zero(Fp28& r) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = 0;
 }
-__device__ __forceinline__ void f2_add(F2& r, const F2& a, const F2& b) { f_add(r.c0, a.c0, b.c0); f_add(r.c1, a.c1, b.c1); }
-__device__ __forceinline__ void f2_sub(F2& r, const F2& a, const F2& b) { f_sub(r.c0, a.c0, b.c0); f_sub(r.c1, a.c1, b.c1); }
-__device__ __forceinline__ void f2_dbl(F2& r, const F2& a) { f2_add(r, a, a); }
-__device__ __forceinline__ void f2_neg(F2& r, const F2& a) {
-#pragma unroll
-    for (int i = 0; i < NL; i++) { r.c0.l[i] = -a.c0.l[i]; r.c1.l[i] = -a.c1.l[i]; }
-}
-// renormalise the VALUE into (-0.51p, 0.51p); keeps every thread-level operand small
-__device__ __forceinline__ void f2_vred(F2& r) { vred(r.c0.l); vred(r.c1.l); }
-
-// lazy Fp2 product: each output coefficient is two products in one accumulator, one reduction
-__device__ __attribute__((noinline)) void f2_mul(F2* r, const F2* a, const F2* b) {
-    Acc acc;
-    int32_t n[NL];
-    F2 o;
-    acc_zero(acc);
-    acc_mul(acc, a->c0.l, b->c0.l);
-#pragma unroll
-    for (int i = 0; i < NL; i++) n[i] = -a->c1.l[i];
-    acc_mul(acc, n, b->c1.l);
-    acc_reduce(o.c0.l, acc);
-    acc_zero(acc);
-    acc_mul(acc, a->c0.l, b->c1.l);
-    acc_mul(acc, a->c1.l, b->c0.l);
-    acc_reduce(o.c1.l, acc);
-    *r = o;
-}
-__device__ __attribute__((noinline)) void f2_sqr(F2* r, const F2* a) {
-    Acc acc;
-    int32_t s[NL], d[NL];
-    F2 o;
-#pragma unroll
-    for (int i = 0; i < NL; i++) { s[i] = a->c0.l[i] + a->c1.l[i]; d[i] = a->c0.l[i] - a->c1.l[i]; }
-    acc_zero(acc);
-    acc_mul(acc, s, d);
-    acc_reduce(o.c0.l, acc);
-#pragma unroll
-    for (int i = 0; i < NL; i++) s[i] = 2 * a->c0.l[i];
-    acc_zero(acc);
-    acc_mul(acc, s, a->c1.l);
-    acc_reduce(o.c1.l, acc);
-    *r = o;
-}
 __device__ __attribute__((noinline)) void f_mul_ni(Fp28* r, const Fp28* a, const Fp28* b) { fp28_mul(*r, *a, *b); }
 
 __device__ __forceinline__ void rec_store(int4* dst, const Fp28& x) {
@@ -368,154 +323,182 @@ __device__ __forceinline__ void rec_load(Fp28& x, const int4* src) {
     x.l[8] = v2.x; x.l[9] = v2.y; x.l[10] = v2.z; x.l[11] = v2.w; x.l[12] = v3.x; x.l[13] = v3.y;
 }
 
-struct G2J { F2 x, y, z; };
+// ---- two lanes per pair: lane parity c selects the Fp2 coefficient a value's lane holds ------------------
+// An Fp2 value is ONE Fp28 per lane (c = 0: real part, c = 1: imaginary part); add/sub/neg/dbl touch
+// only the lane's own coefficient; products fetch the partner's coefficient with a DPP quad swap.
+__device__ __forceinline__ void swap_pair(Fp28& o, const Fp28& x) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) o.l[i] = __builtin_amdgcn_update_dpp(0, x.l[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+}
+// r = coefficient c of (a0 + a1 u)^2 :  c=0: (a0 + a1)(a0 - a1) ;  c=1: (2 a0) a1
+// Operands and results travel BY VALUE (VGPRs): with pointers every temporary lives in scratch memory and
+// the kernel becomes HBM-bound on its own stack traffic (measured: 50 GB per 2^17 pairs).
+__device__ __attribute__((noinline)) Fp28 c_sqr(Fp28 mine, int c) {
+    Fp28 o, r;
+    swap_pair(o, mine);
+    int32_t x[NL], y[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        x[i] = o.l[i] + (c ? o.l[i] : mine.l[i]);
+        y[i] = mine.l[i] - (c ? 0 : o.l[i]);
+    }
+    Acc acc;
+    acc_zero(acc);
+    acc_mul(acc, x, y);
+    acc_reduce(r.l, acc);
+    return r;
+}
+// r = coefficient c of (a0 + a1 u)(b0 + b1 u) :  c=0: a0 b0 - a1 b1 ;  c=1: a0 b1 + a1 b0  (one reduction)
+__device__ __attribute__((noinline)) Fp28 c_mul(Fp28 ma, Fp28 mb, int c) {
+    Fp28 ao, bo, r;
+    swap_pair(ao, ma);
+    swap_pair(bo, mb);
+    int32_t x1[NL], x2[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        x1[i] = c ? ao.l[i] : ma.l[i];
+        x2[i] = c ? ma.l[i] : -ao.l[i];
+    }
+    Acc acc;
+    acc_zero(acc);
+    acc_mul(acc, x1, mb.l);
+    acc_mul(acc, x2, bo.l);
+    acc_reduce(r.l, acc);
+    return r;
+}
+__device__ __attribute__((noinline)) Fp28 f_mul_v(Fp28 a, Fp28 b) {
+    Fp28 r;
+    fp28_mul(r, a, b);
+    return r;
+}
+__device__ __forceinline__ Fp28 c_add(const Fp28& a, const Fp28& b) { Fp28 r; f_add(r, a, b); return r; }
+__device__ __forceinline__ Fp28 c_sub(const Fp28& a, const Fp28& b) { Fp28 r; f_sub(r, a, b); return r; }
+__device__ __forceinline__ Fp28 c_dbl(const Fp28& a) { Fp28 r; f_add(r, a, a); return r; }
+__device__ __forceinline__ Fp28 c_neg(const Fp28& a) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = -a.l[i];
+    return r;
+}
 
-// ePrint 2010/354 Alg. 26; returns the line as (c0, c1, c2) and advances r
-__device__ __attribute__((noinline)) void dbl_step(F2* l0, F2* l1, F2* l2, G2J* r) {
-    F2 tmp0, tmp1, tmp2, tmp3, tmp4, tmp5, tmp6, zsq, nx, ny, nz, t;
-    f2_sqr(&tmp0, &r->x);
-    f2_sqr(&tmp1, &r->y);
-    f2_sqr(&tmp2, &tmp1);
-    f2_add(t, tmp1, r->x);
-    f2_sqr(&tmp3, &t);
-    f2_sub(tmp3, tmp3, tmp0);
-    f2_sub(tmp3, tmp3, tmp2);
-    f2_dbl(tmp3, tmp3);
-    f2_add(tmp4, tmp0, tmp0);
-    f2_add(tmp4, tmp4, tmp0);
-    f2_add(tmp6, r->x, tmp4);
-    f2_sqr(&tmp5, &tmp4);
-    f2_sqr(&zsq, &r->z);
-    f2_sub(nx, tmp5, tmp3);
-    f2_sub(nx, nx, tmp3);
-    f2_add(nz, r->z, r->y);
-    f2_sqr(&nz, &nz);
-    f2_sub(nz, nz, tmp1);
-    f2_sub(nz, nz, zsq);
-    f2_sub(ny, tmp3, nx);
-    f2_mul(&ny, &ny, &tmp4);
-    f2_dbl(tmp2, tmp2); f2_dbl(tmp2, tmp2); f2_dbl(tmp2, tmp2);
-    f2_sub(ny, ny, tmp2);
-    f2_mul(&tmp3, &tmp4, &zsq);
-    f2_dbl(tmp3, tmp3);
-    f2_neg(tmp3, tmp3);
-    f2_sqr(&tmp6, &tmp6);
-    f2_sub(tmp6, tmp6, tmp0);
-    f2_sub(tmp6, tmp6, tmp5);
-    f2_dbl(tmp1, tmp1); f2_dbl(tmp1, tmp1);
-    f2_sub(tmp6, tmp6, tmp1);
-    f2_mul(&tmp0, &nz, &zsq);
-    f2_dbl(tmp0, tmp0);
-    f2_vred(nx); f2_vred(ny); f2_vred(nz);
-    r->x = nx; r->y = ny; r->z = nz;
-    *l0 = tmp0; *l1 = tmp3; *l2 = tmp6;
+struct G2C { Fp28 x, y, z; };   // this lane's coefficient of the three Jacobian coordinates
+
+// ePrint 2010/354 Alg. 26; returns this lane's coefficient of the line (c0, c1, c2) and advances r
+__device__ __forceinline__ void dbl_step(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, int c) {
+    Fp28 tmp0 = c_sqr(r.x, c);
+    Fp28 tmp1 = c_sqr(r.y, c);
+    Fp28 tmp2 = c_sqr(tmp1, c);
+    Fp28 tmp3 = c_sqr(c_add(tmp1, r.x), c);
+    tmp3 = c_sub(c_sub(tmp3, tmp0), tmp2);
+    tmp3 = c_dbl(tmp3);
+    Fp28 tmp4 = c_add(c_add(tmp0, tmp0), tmp0);
+    Fp28 tmp6 = c_add(r.x, tmp4);
+    Fp28 tmp5 = c_sqr(tmp4, c);
+    Fp28 zsq = c_sqr(r.z, c);
+    Fp28 nx = c_sub(c_sub(tmp5, tmp3), tmp3);
+    Fp28 nz = c_sqr(c_add(r.z, r.y), c);
+    nz = c_sub(c_sub(nz, tmp1), zsq);
+    Fp28 ny = c_mul(c_sub(tmp3, nx), tmp4, c);
+    tmp2 = c_dbl(c_dbl(c_dbl(tmp2)));
+    ny = c_sub(ny, tmp2);
+    tmp3 = c_neg(c_dbl(c_mul(tmp4, zsq, c)));
+    tmp6 = c_sqr(tmp6, c);
+    tmp6 = c_sub(c_sub(tmp6, tmp0), tmp5);
+    tmp6 = c_sub(tmp6, c_dbl(c_dbl(tmp1)));
+    tmp0 = c_dbl(c_mul(nz, zsq, c));
+    vred(nx.l); vred(ny.l); vred(nz.l);
+    r.x = nx; r.y = ny; r.z = nz;
+    l0 = tmp0; l1 = tmp3; l2 = tmp6;
 }
 // ePrint 2010/354 Alg. 27
-__device__ __attribute__((noinline)) void add_step(F2* l0, F2* l1, F2* l2, G2J* r, const F2* qx, const F2* qy) {
-    F2 zsq, ysq, t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, nx, ny, nz, ztsq;
-    f2_sqr(&zsq, &r->z);
-    f2_sqr(&ysq, qy);
-    f2_mul(&t0, &zsq, qx);
-    f2_add(t1, *qy, r->z);
-    f2_sqr(&t1, &t1);
-    f2_sub(t1, t1, ysq);
-    f2_sub(t1, t1, zsq);
-    f2_mul(&t1, &t1, &zsq);
-    f2_sub(t2, t0, r->x);
-    f2_sqr(&t3, &t2);
-    f2_dbl(t4, t3);
-    f2_dbl(t4, t4);
-    f2_mul(&t5, &t4, &t2);
-    f2_sub(t6, t1, r->y);
-    f2_sub(t6, t6, r->y);
-    f2_mul(&t9, &t6, qx);
-    f2_mul(&t7, &t4, &r->x);
-    f2_sqr(&nx, &t6);
-    f2_sub(nx, nx, t5);
-    f2_sub(nx, nx, t7);
-    f2_sub(nx, nx, t7);
-    f2_add(nz, r->z, t2);
-    f2_sqr(&nz, &nz);
-    f2_sub(nz, nz, zsq);
-    f2_sub(nz, nz, t3);
-    f2_add(t10, *qy, nz);
-    f2_sub(t8, t7, nx);
-    f2_mul(&t8, &t8, &t6);
-    f2_mul(&t0, &r->y, &t5);
-    f2_dbl(t0, t0);
-    f2_sub(ny, t8, t0);
-    f2_sqr(&t10, &t10);
-    f2_sub(t10, t10, ysq);
-    f2_sqr(&ztsq, &nz);
-    f2_sub(t10, t10, ztsq);
-    f2_dbl(t9, t9);
-    f2_sub(t9, t9, t10);
-    f2_dbl(t10, nz);
-    f2_neg(t6, t6);
-    f2_dbl(t1, t6);
-    f2_vred(nx); f2_vred(ny); f2_vred(nz);
-    r->x = nx; r->y = ny; r->z = nz;
-    *l0 = t10; *l1 = t1; *l2 = t9;
+__device__ __forceinline__ void add_step(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, const Fp28& qx, const Fp28& qy, int c) {
+    Fp28 zsq = c_sqr(r.z, c);
+    Fp28 ysq = c_sqr(qy, c);
+    Fp28 t0 = c_mul(zsq, qx, c);
+    Fp28 t1 = c_sqr(c_add(qy, r.z), c);
+    t1 = c_mul(c_sub(c_sub(t1, ysq), zsq), zsq, c);
+    Fp28 t2 = c_sub(t0, r.x);
+    Fp28 t3 = c_sqr(t2, c);
+    Fp28 t4 = c_dbl(c_dbl(t3));
+    Fp28 t5 = c_mul(t4, t2, c);
+    Fp28 t6 = c_sub(c_sub(t1, r.y), r.y);
+    Fp28 t9 = c_mul(t6, qx, c);
+    Fp28 t7 = c_mul(t4, r.x, c);
+    Fp28 nx = c_sqr(t6, c);
+    nx = c_sub(c_sub(c_sub(nx, t5), t7), t7);
+    Fp28 nz = c_sqr(c_add(r.z, t2), c);
+    nz = c_sub(c_sub(nz, zsq), t3);
+    Fp28 t10 = c_add(qy, nz);
+    Fp28 t8 = c_mul(c_sub(t7, nx), t6, c);
+    t0 = c_dbl(c_mul(r.y, t5, c));
+    Fp28 ny = c_sub(t8, t0);
+    t10 = c_sub(c_sqr(t10, c), ysq);
+    t10 = c_sub(t10, c_sqr(nz, c));
+    t9 = c_sub(c_dbl(t9), t10);
+    t10 = c_dbl(nz);
+    t6 = c_neg(t6);
+    t1 = c_dbl(t6);
+    vred(nx.l); vred(ny.l); vred(nz.l);
+    r.x = nx; r.y = ny; r.z = nz;
+    l0 = t10; l1 = t1; l2 = t9;
 }
 
-// one lane per pair: write the 68-step line stream of pair `pid` (check = pid / k, j = pid % k)
-__global__ void __launch_bounds__(64) k_prep_lines(const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
-                                                    uint32_t n_pairs, uint32_t k, uint32_t nc, int4* lines) {
-    const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
-    if (pid >= n_pairs) return;
+// two lanes per pair: write the 68-step line stream of pair `pid` (check = pid / k, j = pid % k);
+// lane c writes the records of Fp2 coefficient c
+#ifndef ZKP_PREP_WAVES
+#define ZKP_PREP_WAVES 2   // measured: 256 VGPRs (2 waves/SIMD) 6.6 ms, 168 -> 9.3 ms, 128 -> 11.4 ms per 2^17 pairs (spill traffic)
+#endif
+__global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
+                                                       uint32_t n_pairs, uint32_t k, uint32_t nc, int4* lines) {
+    const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
+    const int c = (int)(tid & 1);
+    uint32_t pid = tid >> 1;
+    const bool live_lane = pid < n_pairs;
+    if (!live_lane) pid = n_pairs - 1;   // keep both lanes of a pair (and the DPP swaps) well defined
     const uint32_t check = pid / k, j = pid - check * k;
     const bool dead = (inf1 && inf1[pid]) || (inf2 && inf2[pid]);
-    auto rec = [&](uint32_t step, uint32_t c) -> int4* { return lines + ((((size_t)step * k + j) * 6 + c) * nc + check) * 4; };
-    if (dead) {  // neutral line: f * (1 + 0 v + 0 v w) = f
-        Fp28 one, zero;
-        f_set(one, K28_ONE);
-        f_zero(zero);
-        for (uint32_t s = 0; s < (uint32_t)NLINES; s++) {
-            rec_store(rec(s, 0), one);
-            for (uint32_t c = 1; c < 6; c++) rec_store(rec(s, c), zero);
-        }
-        return;
-    }
-    Fp28 px, py;
-    F2 qx, qy;
+    auto rec = [&](uint32_t step, uint32_t e) -> int4* { return lines + ((((size_t)step * k + j) * 6 + e) * nc + check) * 4; };
+    Fp28 px, py, qx, qy;
     fp28_from_wire(px, g1 + 12 * (size_t)pid);
     fp28_from_wire(py, g1 + 12 * (size_t)pid + 6);
-    fp28_from_wire(qx.c0, g2 + 24 * (size_t)pid);
-    fp28_from_wire(qx.c1, g2 + 24 * (size_t)pid + 6);
-    fp28_from_wire(qy.c0, g2 + 24 * (size_t)pid + 12);
-    fp28_from_wire(qy.c1, g2 + 24 * (size_t)pid + 18);
-    G2J r;
+    fp28_from_wire(qx, g2 + 24 * (size_t)pid + 6 * c);
+    fp28_from_wire(qy, g2 + 24 * (size_t)pid + 12 + 6 * c);
+    G2C r;
     r.x = qx;
     r.y = qy;
-    f_set(r.z.c0, K28_ONE);
-    f_zero(r.z.c1);
+    if (c == 0) f_set(r.z, K28_ONE); else f_zero(r.z);
     uint32_t step = 0;
-    auto emit = [&](F2& l0, F2& l1, F2& l2) {
-        // stream order (c2, c1 * xP, c0 * yP) = the (c0, c1, c4) operands of mul_by_014
-        Fp28 t;
-        vred(l2.c0.l); vred(l2.c1.l);
-        rec_store(rec(step, 0), l2.c0);
-        rec_store(rec(step, 1), l2.c1);
-        f_mul_ni(&t, &l1.c0, &px); rec_store(rec(step, 2), t);
-        f_mul_ni(&t, &l1.c1, &px); rec_store(rec(step, 3), t);
-        f_mul_ni(&t, &l0.c0, &py); rec_store(rec(step, 4), t);
-        f_mul_ni(&t, &l0.c1, &py); rec_store(rec(step, 5), t);
+    Fp28 one_or_zero;
+    if (c == 0) f_set(one_or_zero, K28_ONE); else f_zero(one_or_zero);
+    auto emit = [&](Fp28& l0, Fp28& l1, Fp28& l2) {
+        // stream order (c2, c1 * xP, c0 * yP) = the (c0, c1, c4) operands of mul_by_014; a pair with an
+        // infinity streams the neutral line (1, 0, 0)
+        vred(l2.l);
+        Fp28 t1 = f_mul_v(l1, px);
+        Fp28 t0 = f_mul_v(l0, py);
+        if (live_lane) {
+            Fp28 z;
+            f_zero(z);
+            rec_store(rec(step, 0 + c), dead ? one_or_zero : l2);
+            rec_store(rec(step, 2 + c), dead ? z : t1);
+            rec_store(rec(step, 4 + c), dead ? z : t0);
+        }
         step++;
     };
-    F2 l0, l1, l2;
+    Fp28 l0, l1, l2;
     const uint64_t xs = 0xd201000000010000ULL >> 1;
     bool found = false;
     for (int b = 63; b >= 0; b--) {
         const bool bit = (xs >> b) & 1;
         if (!found) { found = bit; continue; }
-        dbl_step(&l0, &l1, &l2, &r);
+        dbl_step(l0, l1, l2, r, c);
         emit(l0, l1, l2);
         if (bit) {
-            add_step(&l0, &l1, &l2, &r, &qx, &qy);
+            add_step(l0, l1, l2, r, qx, qy, c);
             emit(l0, l1, l2);
         }
     }
-    dbl_step(&l0, &l1, &l2, &r);
+    dbl_step(l0, l1, l2, r, c);
     emit(l0, l1, l2);
 }
 
@@ -650,7 +633,7 @@ static hipError_t prep(CoopDev* d, const uint64_t* g1, const uint64_t* g2, const
     if (e != hipSuccess) return e;
     size_t p0 = base_check * k;
     uint32_t n_pairs = n * k;
-    hipLaunchKernelGGL(k_prep_lines, dim3((n_pairs + 63) / 64), dim3(64), 0, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
+    hipLaunchKernelGGL(k_prep_lines, dim3((2 * n_pairs + 63) / 64), dim3(64), 0, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
                        i2 ? i2 + p0 : nullptr, n_pairs, k, n, d->lines);
     return hipGetLastError();
 }
