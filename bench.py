@@ -88,6 +88,11 @@ def main():
     if rank == 0:
         value = world * n * args.steps / dt
         achieved = (n * MACS_PER_PAIRING) / (kern_ms * 1e-3)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01", "pmc", "traffic.json")
+        if os.path.exists(tpath) and n == PAIRS_PER_GPU and args.kernel in ("auto", "coop"):
+            with open(tpath) as tf:   # rocprofv3 PMC passes of this same command, gfx950-corrected (see file)
+                traffic = json.load(tf)["hbm_bytes_per_step"]
         # bit-exact parity of a seeded sample vs the CPU oracle + timing of the oracle on the host cores
         cpu = None
         parity = None
@@ -116,7 +121,7 @@ def main():
                        "gt_sample_bit_exact": parity},
             "roofline": {"bound": "valu-int (neither hbm nor mfma: 384-bit modular arithmetic, >7000 MAC/B)",
                          "achieved": achieved / 1e12, "peak": PEAK_MACS / 1e12, "unit": "T u32-MAC/s",
-                         "frac": achieved / PEAK_MACS, "traffic": None,
+                         "frac": achieved / PEAK_MACS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_macs_per_pairing": MACS_PER_PAIRING},
             "cpu_baseline": cpu,
         }

@@ -126,6 +126,10 @@ int zkp_g2_mul_batch_dev(zkp_ctx* ctx, const void* d_base, size_t base_stride, c
 int zkp_time_pairing_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out_gt, int reps,
                          float* avg_ms);
 
+/* diagnostic: time one synthetic step program of the cooperative interpreter (which: 0 T=1, 1 T=3,
+ * 2 T=3+epilogue, 3 T=6, 4 T=12, 5 LIN; 400 iterations each) over n checks; used by tools/ only. */
+int zkp_time_coop_step(zkp_ctx* ctx, int which, size_t n, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,6 +217,24 @@ def test_properties_at_size(keng):
     assert np.array_equal(keng.pairing(g1[sel], g2[sel]), o.pairing_batch(g1[sel], g2[sel], nthreads=NTHREADS))
 
 
+def test_config2_full_batch_bit_exact(eng):
+    """BASELINE.json config 2: 2^16 random (G1,G2) pairs on one GPU, EVERY Gt compared with the CPU oracle."""
+    import hashlib
+    from zkvm_pairings_amd import synthetic
+    n = 1 << 16
+    g1, g2, _, _ = synthetic.random_pairs(eng, n, seed=synthetic.SEED)
+    got = eng.pairing(g1, g2)
+    want = o.pairing_batch(g1, g2, nthreads=NTHREADS)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
+    assert np.array_equal(got, want)
+    ok, allok = eng.pairing_check(g1, g2, 1)
+    assert not ok.any() and not allok
+    # every infinity flag set => every pairing is the identity and the AND flag is true (SURVEY 8d)
+    inf = np.ones(n, dtype=np.uint8)
+    ok, allok = eng.pairing_check(g1, g2, 1, inf, None)
+    assert ok.all() and allok
+
+
 def test_bilinearity_on_gpu(keng):
     from zkvm_pairings_amd import synthetic
     a, b = 0x1234567, 0x89ABCDE

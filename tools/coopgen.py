@@ -1032,6 +1032,40 @@ def encode(builder):
     return hdr, tbl
 
 
+def prog_timing(T, epi, nloop=400, lin=False):
+    """synthetic timing program (not a meaningful computation): LOOP nloop { MULACC with T two-term products
+    per lane (+ epilogue) } or { LIN with 3 terms }"""
+    b = Builder()
+    v = b.alloc(12)
+    w = b.alloc(12)
+    b.lin([(v[i], Lin.of(CONST_SLOT["ONE"])) for i in range(12)])
+    b.lin([(w[i], Lin.of(CONST_SLOT["F1_1_0"])) for i in range(12)])
+    b.loop(nloop)
+    if lin:
+        b.lin([(v[i], Lin({v[i]: 1, w[(i + 1) % 12]: 1, w[(i + 5) % 12]: -1})) for i in range(12)])
+    else:
+        outs = []
+        for i in range(12):
+            bil = Bil([(Lin({v[(i + t) % 12]: 1, w[(i + t + 3) % 12]: 1}), Lin({w[(i + 2 * t) % 12]: 1, v[(i + t + 7) % 12]: -1}), 1) for t in range(T)])
+            o = {"dst": v[i], "bil": bil}
+            if epi:
+                o.update(alpha=3, beta=-2, e=v[i])
+            outs.append(o)
+        b.steps_before = len(b.steps)
+        # bypass merge_terms so that exactly T two-term products are emitted
+        lanes = []
+        for o in outs:
+            enc = []
+            for a_, b_, c_ in o["bil"]:
+                ea, eb = encode_form(a_), encode_form(b_)
+                enc.append((ea[0], ea[1], ea[2], eb[0], eb[1], eb[2], bool(ea[3]) ^ bool(eb[3])))
+            lanes.append({"dst": o["dst"], "terms": enc, "alpha": o.get("alpha", 1), "beta": o.get("beta", 0), "e": o.get("e", ZERO)})
+        b.steps.append({"op": OP_MULACC, "T": T, "lanes": lanes, "epi": bool(epi)})
+    b.endloop()
+    b.gstore(K_STATE, [(v[i], i) for i in range(12)])
+    return b
+
+
 PROGRAMS = {
     "miller1_state": lambda: prog_miller(1, False),
     "miller1_wire": lambda: prog_miller(1, True),
@@ -1044,6 +1078,12 @@ PROGRAMS = {
     "fexp_a_state": lambda: prog_fexp_a(False),
     "fexp_a_wire": lambda: prog_fexp_a(True),
     "fexp_c": lambda: prog_fexp_c(True),
+    "time_t1": lambda: prog_timing(1, False),
+    "time_t3": lambda: prog_timing(3, False),
+    "time_t3e": lambda: prog_timing(3, True),
+    "time_t6": lambda: prog_timing(6, False),
+    "time_t12": lambda: prog_timing(12, False),
+    "time_lin": lambda: prog_timing(0, False, lin=True),
 }
 
 

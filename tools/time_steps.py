@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Per-step cost of the cooperative interpreter from synthetic programs (400 iterations each)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import zkvm_pairings_amd as z
+eng = z.PairingEngine(0)
+n = 1 << 16
+names = ["T=1", "T=3", "T=3+epi", "T=6", "T=12", "LIN"]
+res = {}
+for i, nm in enumerate(names):
+    ms = ctypes.c_float()
+    rc = eng._lib.zkp_time_coop_step(eng._h, i, n, ctypes.byref(ms))
+    assert rc == 0, rc
+    waves = (n + 4) // 5
+    per_simd = waves / 1024.0
+    # cycles per step per SIMD-wave-slot at 2.1 GHz: time * f / (iterations * waves per SIMD)
+    cyc = ms.value * 1e-3 * 2.1e9 / (400 * per_simd)
+    res[nm] = cyc
+    print("%-8s %.3f ms  => %.0f SIMD-cycles per step (at 2.1 GHz)" % (nm, ms.value, cyc))
+P = (res["T=12"] - res["T=6"]) / 6
+print("P (per product block) = %.0f ; R (T=1 minus P) = %.0f ; epilogue = %.0f ; LIN = %.0f" % (P, res["T=1"] - P, res["T=3+epi"] - res["T=3"], res["LIN"]))

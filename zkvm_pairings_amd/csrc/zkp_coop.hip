@@ -19,6 +19,7 @@
 #include "zkp_coop.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "zkp_coop_prog.inc"
@@ -309,7 +310,6 @@ __device__ __forceinline__ void f_zero(Fp28& r) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = 0;
 }
-__device__ __attribute__((noinline)) void f_mul_ni(Fp28* r, const Fp28* a, const Fp28* b) { fp28_mul(*r, *a, *b); }
 
 __device__ __forceinline__ void rec_store(int4* dst, const Fp28& x) {
     dst[0] = make_int4(x.l[0], x.l[1], x.l[2], x.l[3]);
@@ -510,11 +510,13 @@ __global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks
     rec_load(a, state + ((size_t)ZKP_COOP_ST_N * nc + i) * 4);
     f_set(res, K28_ONE);
     // p - 2 in 28-bit limbs: p's limbs with 2 subtracted from limb 0 (no borrow: limb 0 = 0xfffaaab)
+#pragma unroll 1
     for (int w = NL - 1; w >= 0; w--) {
-        uint32_t e = (uint32_t)K28_P[w] - (w == 0 ? 2u : 0u);
+        const uint32_t e = (uint32_t)K28_P[w] - (w == 0 ? 2u : 0u);
+#pragma unroll 1
         for (int b = W - 1; b >= 0; b--) {
-            f_mul_ni(&res, &res, &res);
-            if ((e >> b) & 1) f_mul_ni(&res, &res, &a);
+            fp28_mul(res, res, res);
+            if ((e >> b) & 1) fp28_mul(res, res, a);   // wave-uniform branch: the exponent is a constant
         }
     }
     rec_store(state + ((size_t)ZKP_COOP_ST_NINV * nc + i) * 4, res);
@@ -537,14 +539,21 @@ __global__ void k_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint6
 namespace zkp {
 
 struct CoopProgDev { uint32_t* hdr; uint32_t* tbl; uint32_t nslot; };
+constexpr int MAX_PIPES = 4;
+struct CoopPipe {            // one in-flight chunk: its own workspace and (for pipes > 0) its own stream
+    int4* lines;  size_t lines_bytes;
+    int4* state;  size_t state_bytes;
+    hipStream_t stream;
+    hipEvent_t done;
+};
 struct CoopDev {
     CoopProgDev progs[ZKP_PROG_COUNT];
     int4* consts;
-    int4* lines;  size_t lines_bytes;
-    int4* state;  size_t state_bytes;
+    CoopPipe pipe[MAX_PIPES];
+    int n_pipes;
+    size_t chunk;            // checks per pipeline pass (bounds the line-stream workspace: 26 KB per pair)
+    hipEvent_t ready;
 };
-
-static const size_t CHUNK = 1 << 17;   // checks per pipeline pass (bounds the line-stream workspace: 26 KB per pair)
 
 hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     st->cus = prop.multiProcessorCount;
@@ -561,6 +570,20 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     }
     if ((e = hipMalloc((void**)&d->consts, sizeof(ZKP_COOP_CONSTS))) != hipSuccess) return e;
     if ((e = hipMemcpy(d->consts, ZKP_COOP_CONSTS, sizeof(ZKP_COOP_CONSTS), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    // chunks of a batch are processed by n_pipes independent pipelines on separate HIP streams so that the
+    // tail of one kernel (and the latency-bound inversion) overlaps the next chunk's work
+    const char* ev = getenv("ZKP_COOP_STREAMS");
+    d->n_pipes = ev ? atoi(ev) : 2;
+    if (d->n_pipes < 1) d->n_pipes = 1;
+    if (d->n_pipes > MAX_PIPES) d->n_pipes = MAX_PIPES;
+    ev = getenv("ZKP_COOP_CHUNK");
+    d->chunk = ev ? (size_t)atol(ev) : ((size_t)1 << 16);   // measured best: 2 pipes x 2^16 checks
+    if (d->chunk < 320) d->chunk = 320;
+    for (int i = 0; i < d->n_pipes; i++) {
+        if ((e = hipStreamCreateWithFlags(&d->pipe[i].stream, hipStreamNonBlocking)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&d->pipe[i].done, hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    if ((e = hipEventCreateWithFlags(&d->ready, hipEventDisableTiming)) != hipSuccess) return e;
     st->d_prog = d;
     st->available = true;
     return hipSuccess;
@@ -574,8 +597,13 @@ void coop_free(CoopState* st) {
         if (d->progs[i].tbl) (void)hipFree(d->progs[i].tbl);
     }
     if (d->consts) (void)hipFree(d->consts);
-    if (d->lines) (void)hipFree(d->lines);
-    if (d->state) (void)hipFree(d->state);
+    for (int i = 0; i < MAX_PIPES; i++) {
+        if (d->pipe[i].lines) (void)hipFree(d->pipe[i].lines);
+        if (d->pipe[i].state) (void)hipFree(d->pipe[i].state);
+        if (d->pipe[i].stream) (void)hipStreamDestroy(d->pipe[i].stream);
+        if (d->pipe[i].done) (void)hipEventDestroy(d->pipe[i].done);
+    }
+    if (d->ready) (void)hipEventDestroy(d->ready);
     delete d;
     st->d_prog = nullptr;
     st->available = false;
@@ -592,14 +620,15 @@ static hipError_t ensure_buf(int4** p, size_t* cap, size_t bytes) {
     return e;
 }
 
-static hipError_t run_prog(CoopDev* d, int prog, uint32_t n_checks, uint32_t nc, uint32_t k, const uint64_t* wire_in, uint64_t* wire_out,
-                           uint8_t* ok, int* all_ok, hipStream_t s) {
+static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks, uint32_t nc, uint32_t k, const uint64_t* wire_in,
+                           uint64_t* wire_out, uint8_t* ok, int* all_ok) {
+    hipStream_t s = pp->stream;
     CoopArgs a;
     a.hdr = d->progs[prog].hdr;
     a.tbl = d->progs[prog].tbl;
     a.consts = d->consts;
-    a.lines = d->lines;
-    a.state = d->state;
+    a.lines = pp->lines;
+    a.state = pp->state;
     a.wire_in = wire_in;
     a.wire_out = wire_out;
     a.ok = ok;
@@ -627,15 +656,45 @@ static int miller_prog(size_t k, bool wire) {
 
 bool coop_supports_k(size_t k) { return k >= 1 && k <= 4; }
 
-static hipError_t prep(CoopDev* d, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t base_check, uint32_t n,
-                       uint32_t k, hipStream_t s) {
-    hipError_t e = ensure_buf(&d->lines, &d->lines_bytes, (size_t)NLINES * k * 6 * n * 64);
-    if (e != hipSuccess) return e;
+static hipError_t prep(CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t base_check, uint32_t n,
+                       uint32_t k) {
+    hipStream_t s = pp->stream;
     size_t p0 = base_check * k;
     uint32_t n_pairs = n * k;
     hipLaunchKernelGGL(k_prep_lines, dim3((2 * n_pairs + 63) / 64), dim3(64), 0, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
-                       i2 ? i2 + p0 : nullptr, n_pairs, k, n, d->lines);
+                       i2 ? i2 + p0 : nullptr, n_pairs, k, n, pp->lines);
     return hipGetLastError();
+}
+
+// Run `body(pipe, base, n)` for every chunk of the batch, round-robin over the pipelines.  The caller's
+// stream `s` is forked into the pipeline streams (they wait for everything already queued on `s`) and
+// joined again at the end, so from the caller's point of view the call is ordered on `s`.
+template <class Body>
+static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lines, hipStream_t s, Body body) {
+    if (!n_total) return hipSuccess;
+    hipError_t e;
+    size_t chunk = d->chunk;
+    int pipes = d->n_pipes;
+    if (n_total <= chunk) pipes = 1;
+    // workspace first: hipMalloc/hipFree synchronise the device, so never (re)allocate between launches
+    size_t cmax = n_total < chunk ? n_total : chunk;
+    for (int i = 0; i < pipes; i++) {
+        if (need_lines && (e = ensure_buf(&d->pipe[i].lines, &d->pipe[i].lines_bytes, (size_t)NLINES * k * 6 * cmax * 64)) != hipSuccess) return e;
+        if ((e = ensure_buf(&d->pipe[i].state, &d->pipe[i].state_bytes, (size_t)ST_SIZE * cmax * 64)) != hipSuccess) return e;
+    }
+    if ((e = hipEventRecord(d->ready, s)) != hipSuccess) return e;
+    for (int i = 0; i < pipes; i++)
+        if ((e = hipStreamWaitEvent(d->pipe[i].stream, d->ready, 0)) != hipSuccess) return e;
+    int c = 0;
+    for (size_t base = 0; base < n_total; base += chunk, c++) {
+        uint32_t n = (uint32_t)((n_total - base) < chunk ? (n_total - base) : chunk);
+        if ((e = body(&d->pipe[c % pipes], base, n)) != hipSuccess) return e;
+    }
+    for (int i = 0; i < pipes; i++) {
+        if ((e = hipEventRecord(d->pipe[i].done, d->pipe[i].stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(s, d->pipe[i].done, 0)) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
@@ -643,32 +702,27 @@ hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, co
     CoopDev* d = (CoopDev*)st->d_prog;
     int prog = miller_prog(k, true);
     if (prog < 0) return hipErrorNotSupported;
-    for (size_t base = 0; base < n_checks; base += CHUNK) {
-        uint32_t n = (uint32_t)((n_checks - base) < CHUNK ? (n_checks - base) : CHUNK);
-        hipError_t e = prep(d, g1, g2, i1, i2, base, n, (uint32_t)k, s);
+    return for_chunks(d, n_checks, k, true, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
+        hipError_t e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k);
         if (e != hipSuccess) return e;
-        if ((e = run_prog(d, prog, n, n, (uint32_t)k, nullptr, out + 72 * base, nullptr, nullptr, s)) != hipSuccess) return e;
-    }
-    return hipSuccess;
+        return run_prog(d, pp, prog, n, n, (uint32_t)k, nullptr, out + 72 * base, nullptr, nullptr);
+    });
 }
 
-static hipError_t fexp_tail(CoopDev* d, uint32_t n, uint64_t* out, uint8_t* ok, int* all_ok, hipStream_t s) {
-    hipLaunchKernelGGL(k_batch_inv, dim3((n + 63) / 64), dim3(64), 0, s, d->state, n, n);
+static hipError_t fexp_tail(CoopDev* d, CoopPipe* pp, uint32_t n, uint64_t* out, uint8_t* ok, int* all_ok) {
+    hipLaunchKernelGGL(k_batch_inv, dim3((n + 63) / 64), dim3(64), 0, pp->stream, pp->state, n, n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return run_prog(d, ZKP_PROG_FEXP_C, n, n, 1, nullptr, out, ok, all_ok, s);
+    return run_prog(d, pp, ZKP_PROG_FEXP_C, n, n, 1, nullptr, out, ok, all_ok);
 }
 
 hipError_t coop_final_exp(CoopState* st, const uint64_t* f, size_t n_total, uint64_t* out, hipStream_t s) {
     CoopDev* d = (CoopDev*)st->d_prog;
-    for (size_t base = 0; base < n_total; base += CHUNK) {
-        uint32_t n = (uint32_t)((n_total - base) < CHUNK ? (n_total - base) : CHUNK);
-        hipError_t e = ensure_buf(&d->state, &d->state_bytes, (size_t)ST_SIZE * n * 64);
+    return for_chunks(d, n_total, 1, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
+        hipError_t e = run_prog(d, pp, ZKP_PROG_FEXP_A_WIRE, n, n, 1, f + 72 * base, nullptr, nullptr, nullptr);
         if (e != hipSuccess) return e;
-        if ((e = run_prog(d, ZKP_PROG_FEXP_A_WIRE, n, n, 1, f + 72 * base, nullptr, nullptr, nullptr, s)) != hipSuccess) return e;
-        if ((e = fexp_tail(d, n, out + 72 * base, nullptr, nullptr, s)) != hipSuccess) return e;
-    }
-    return hipSuccess;
+        return fexp_tail(d, pp, n, out + 72 * base, nullptr, nullptr);
+    });
 }
 
 hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
@@ -676,15 +730,34 @@ hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, c
     CoopDev* d = (CoopDev*)st->d_prog;
     int prog = miller_prog(k, false);
     if (prog < 0) return hipErrorNotSupported;
-    for (size_t base = 0; base < n_checks; base += CHUNK) {
-        uint32_t n = (uint32_t)((n_checks - base) < CHUNK ? (n_checks - base) : CHUNK);
-        hipError_t e = ensure_buf(&d->state, &d->state_bytes, (size_t)ST_SIZE * n * 64);
+    return for_chunks(d, n_checks, k, true, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
+        hipError_t e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k);
         if (e != hipSuccess) return e;
-        if ((e = prep(d, g1, g2, i1, i2, base, n, (uint32_t)k, s)) != hipSuccess) return e;
-        if ((e = run_prog(d, prog, n, n, (uint32_t)k, nullptr, nullptr, nullptr, nullptr, s)) != hipSuccess) return e;
-        if ((e = run_prog(d, ZKP_PROG_FEXP_A_STATE, n, n, 1, nullptr, nullptr, nullptr, nullptr, s)) != hipSuccess) return e;
-        if ((e = fexp_tail(d, n, out_gt ? out_gt + 72 * base : nullptr, ok ? ok + base : nullptr, all_ok, s)) != hipSuccess) return e;
-    }
+        if ((e = run_prog(d, pp, prog, n, n, (uint32_t)k, nullptr, nullptr, nullptr, nullptr)) != hipSuccess) return e;
+        if ((e = run_prog(d, pp, ZKP_PROG_FEXP_A_STATE, n, n, 1, nullptr, nullptr, nullptr, nullptr)) != hipSuccess) return e;
+        return fexp_tail(d, pp, n, out_gt ? out_gt + 72 * base : nullptr, ok ? ok + base : nullptr, all_ok);
+    });
+}
+
+// timing hook: run one of the synthetic programs (tools/coopgen.py prog_timing) over n checks
+hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, float* ms) {
+    CoopDev* d = (CoopDev*)st->d_prog;
+    static const int ids[6] = {ZKP_PROG_TIME_T1, ZKP_PROG_TIME_T3, ZKP_PROG_TIME_T3E, ZKP_PROG_TIME_T6, ZKP_PROG_TIME_T12, ZKP_PROG_TIME_LIN};
+    if (which < 0 || which >= 6) return hipErrorInvalidValue;
+    CoopPipe* pp = &d->pipe[0];
+    hipError_t e = ensure_buf(&pp->state, &pp->state_bytes, (size_t)ST_SIZE * n * 64);
+    if (e != hipSuccess) return e;
+    hipEvent_t e0, e1;
+    if ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess) return e;
+    (void)s;
+    if ((e = run_prog(d, pp, ids[which], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr)) != hipSuccess) return e;
+    (void)hipEventRecord(e0, pp->stream);
+    if ((e = run_prog(d, pp, ids[which], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr)) != hipSuccess) return e;
+    (void)hipEventRecord(e1, pp->stream);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return hipSuccess;
 }
 

@@ -619,6 +619,14 @@ int zkp_fp_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, si
     return ZKP_OK;
 }
 
+int zkp_time_coop_step(zkp_ctx* c, int which, size_t n, float* ms) {
+    if (!c || !ms) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    HIPCHK(c, zkp::coop_time_prog(&c->coop, which, n, c->stream, ms));
+    return ZKP_OK;
+}
+
 int zkp_time_pairing_dev(zkp_ctx* c, const void* g1, const void* g2, size_t n, void* out, int reps, float* avg_ms) {
     if (!c || !g1 || !g2 || !out || reps <= 0 || !avg_ms) return ZKP_ERR_ARG;
     int rc = bind(c);
