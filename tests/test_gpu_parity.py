@@ -235,6 +235,36 @@ def test_config2_full_batch_bit_exact(eng):
     assert ok.all() and allok
 
 
+def test_final_exponentiation_of_arbitrary_fp12(keng):
+    """final_exponentiation must agree with the oracle on ANY invertible Fp12 (not only Miller outputs),
+    including 1, -1, elements of Fp / Fp2 / Fp6 embedded in Fp12 and limbs at the top of the range."""
+    g = m.SplitMix64(0xFE)
+    rows = [[g.below(m.P) for _ in range(12)] for _ in range(40)]
+    rows.append([1] + [0] * 11)
+    rows.append([m.P - 1] + [0] * 11)
+    rows.append([m.P - 1] * 12)
+    rows.append([5] + [0] * 11)
+    rows.append([3, 7] + [0] * 10)
+    rows.append([3, 7, 1, 0, m.P - 2, 9] + [0] * 6)
+    rows.append([0] * 6 + [1] + [0] * 5)
+    f = np.stack([o.ints_to_arr(r) for r in rows])
+    assert np.array_equal(keng.final_exponentiation(f), o.final_exponentiation_batch(f))
+
+
+def test_pairing_of_extreme_points(keng):
+    """points whose coordinates sit at the ends of the canonical range, -P, -Q, and P = Q-independent repeats"""
+    from zkvm_pairings_amd import synthetic
+    g1, g2 = synthetic.G1_GENERATOR, synthetic.G2_GENERATOR
+    negp = g1.copy()
+    negp[6:] = o.fp_neg(g1[6:])
+    negq = g2.copy()
+    negq[12:] = o.fp2_neg(g2[12:])
+    ps = np.stack([g1, negp, g1, negp] + [o.g1_mul(g1, k)[0] for k in (2, 3, m.R_ORDER - 1, m.R_ORDER - 2)])
+    qs = np.stack([g2, g2, negq, negq] + [o.g2_mul(g2, k)[0] for k in (m.R_ORDER - 1, 5, 2, m.R_ORDER - 3)])
+    assert np.array_equal(keng.pairing(ps, qs), o.pairing_batch(ps, qs, nthreads=8))
+    assert np.array_equal(keng.multi_miller_loop(ps, qs, 4), o.multi_miller_loop_batch(ps, qs, 2, 4))
+
+
 def test_bilinearity_on_gpu(keng):
     from zkvm_pairings_amd import synthetic
     a, b = 0x1234567, 0x89ABCDE

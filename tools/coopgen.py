@@ -376,6 +376,16 @@ class Builder:
             lanes.append({"dst": o["dst"], "terms": enc, "alpha": o.get("alpha", 1), "beta": o.get("beta", 0), "e": o.get("e", ZERO)})
         T = max(len(l["terms"]) for l in lanes)
         assert T >= 1
+        # static worst case, valid for EVERY input: every LDS-resident value has |limb| <= 2^27 (+16) except raw
+        # wire limbs (< 2^28); a two-slot form doubles the bound.  sum_t La*Lb*14*2^54 (+ 14*2^56 from m*p)
+        # must stay below 2^63  =>  sum_t La*Lb <= 30.
+        for l in lanes:
+            budget = 0
+            for (a1, a2, asub, b1, b2, bsub, neg) in l["terms"]:
+                la = 1 if (a2 == ZERO) else 2
+                lb = 1 if (b2 == ZERO) else 2
+                budget += la * lb
+            assert budget <= 30, "column budget exceeded: %d" % budget
         epi = [(l["alpha"], l["beta"]) != (1, 0) for l in lanes]
         assert all(epi) or not any(epi), "epilogue must be step-uniform"
         self.steps.append({"op": OP_MULACC, "T": T, "lanes": lanes, "epi": bool(epi[0])})
@@ -792,17 +802,20 @@ def acc_reduce(col):
             assert abs(col[i + j]) < (1 << 63), "column overflow in reduction"
         assert col[i] & ((1 << W) - 1) == 0
         col[i + 1] += col[i] >> W
-    out = []
-    carry = 0
+    # limb k = lo_k + mid_{k-1} + top_{k-2} from the signed 64-bit columns c[14..26], then weak_norm
+    lo, mid, top = [], [], []
     for k in range(NL - 1):
-        v = col[NL + k] + carry
-        lo = lo28s(v)
-        out.append(lo)
-        carry = (v - lo) >> W
-    top = col[2 * NL - 1] + carry
-    assert abs(top) < (1 << 31)
-    out.append(top)
-    return out
+        v = col[NL + k]
+        assert abs(v) < (1 << 63)
+        lo.append(v & ((1 << W) - 1))
+        mid.append((v >> W) & ((1 << W) - 1))
+        top.append(v >> (2 * W))
+    out = [lo[0], lo[1] + mid[0]]
+    for k in range(2, NL - 1):
+        out.append(lo[k] + mid[k - 1] + top[k - 2])
+    out.append(mid[NL - 2] + top[NL - 3] + (top[NL - 2] << W))
+    assert limbs_value(out) == sum(col[NL + k] << (W * k) for k in range(NL - 1))
+    return weak_norm(out)
 
 
 def weak_norm(x):
