@@ -63,7 +63,7 @@ K_LINE, K_STATE, K_WIRE = 0, 1, 2
 def _const_table():
     """name -> true field value (NOT Montgomery); index in the table = slot - CONST_BASE."""
     g = [M.f2_pow(M.XI, i * (P - 1) // 6) for i in range(6)]
-    t = [("ZERO", 0), ("ONE", 1)]
+    t = [("ZERO", 0), ("ONE", 1), ("RAW_R2", None), ("RAW_ONE", None)]
     # Frobenius^j coefficients gamma_{j,i} = gamma_i^(1 + p + ... + p^(j-1)) for w^i, j = 1, 2, 3
     for j in (1, 2, 3):
         for i in range(1, 6):
@@ -79,11 +79,9 @@ def _const_table():
 
 
 CONSTS = _const_table()
+# RAW_R2 / RAW_ONE are "raw" constants for Montgomery conversion: their LIMBS hold R^2 mod p resp. 1
 CONST_SLOT = {name: CONST_BASE + i for i, (name, _) in enumerate(CONSTS)}
-# two special "raw" constants for Montgomery conversion: their LIMBS hold R^2 mod p resp. 1
-CONST_SLOT["RAW_R2"] = CONST_BASE + len(CONSTS)
-CONST_SLOT["RAW_ONE"] = CONST_BASE + len(CONSTS) + 1
-N_CONST = len(CONSTS) + 2
+N_CONST = len(CONSTS)
 assert CONST_BASE + N_CONST <= 128
 ZERO = CONST_SLOT["ZERO"]
 
@@ -543,14 +541,16 @@ def runs(flags):
     return out
 
 
-def emit_line_mul(b, f, k, tmp6):
+def emit_line_mul(b, f, k):
     """for each of the k pairs: load the next line (6 Fp, already scaled by P) and multiply f by it"""
+    tmp6 = b.alloc(6)
     for j in range(k):
         b.gload(K_LINE, [(tmp6[c], (j, c)) for c in range(6)], advance=1 if j == k - 1 else 0)
         l0 = lin2(tmp6[0], tmp6[1])
         l1 = lin2(tmp6[2], tmp6[3])
         l4 = lin2(tmp6[4], tmp6[5])
         f = b.fp12_mul_by_014(f, f, l0, l1, l4)
+    b.release(tmp6)
     return f
 
 
@@ -559,7 +559,6 @@ def prog_miller(k, to_wire):
     Line stream order per step: (c2, c1*xP, c0*yP) == the (c0, c1, c4) arguments of mul_by_014."""
     b = Builder()
     f = b.alloc12()
-    tmp6 = b.alloc(6)
     one = CONST_SLOT["ONE"]
     b.lin([(f.slots[i], Lin.of(one if i == 0 else ZERO)) for i in range(12)])
     for n_plain, has_add in runs(miller_bits()):
@@ -568,16 +567,15 @@ def prog_miller(k, to_wire):
         if body_plain > 0:
             if body_plain > 1:
                 b.loop(body_plain)
-            f = emit_line_mul(b, f, k, tmp6)
+            f = emit_line_mul(b, f, k)
             f = b.fp12_sqr(f, f)
             if body_plain > 1:
                 b.endloop()
         if has_add:
-            f = emit_line_mul(b, f, k, tmp6)
-            f = emit_line_mul(b, f, k, tmp6)
+            f = emit_line_mul(b, f, k)
+            f = emit_line_mul(b, f, k)
             f = b.fp12_sqr(f, f)
-    f = emit_line_mul(b, f, k, tmp6)
-    b.release(tmp6)
+    f = emit_line_mul(b, f, k)
     finish_output(b, f.conj(), to_wire, ST_F)
     return b
 
@@ -612,8 +610,9 @@ ST_C = 12       # 6 : Fp6-inverse cofactors C0..C2
 ST_NC = 18      # 2 : N = (N0, N1) in Fp2
 ST_N = 20       # 1 : n = N0^2 + N1^2 in Fp  (input of the batched inversion kernel)
 ST_NINV = 21    # 1 : n^-1                      (its output)
-ST_SPILL = 24   # 6 x 12 spill areas used by the hard part
-ST_SIZE = ST_SPILL + 6 * 12
+ST_TI = 22      # 6 : t^-1 (Fp6), parked while conj(f)^2 is formed
+ST_SPILL = 28   # 8 x 12 spill areas used by the hard part
+ST_SIZE = ST_SPILL + 8 * 12
 
 
 def prog_fexp_a(from_wire):
@@ -621,10 +620,13 @@ def prog_fexp_a(from_wire):
     src/fp6.rs:291-309, src/fp2.rs:278-296) down to the single Fp inversion."""
     b = Builder()
     f = load_input(b, from_wire, ST_F)
+    if from_wire:
+        b.gstore(K_STATE, [(f.slots[i], ST_F + i) for i in range(12)])
     a0, a1 = f.fp6(0), f.fp6(1)
     # t = a0^2 - v a1^2  (Fp6): lanes 0-5 give a0^2, lanes 6-11 give a1^2
     sq = b.alloc(12)
     b.mulacc([{"dst": sq[i], "bil": bl} for i, bl in enumerate(flatten12(b6_mul(a0, a0), b6_mul(a1, a1)))])
+    b.release(f.slots)
     S0 = tuple(lin2(sq[2 * j], sq[2 * j + 1]) for j in range(3))
     S1 = tuple(lin2(sq[6 + 2 * j], sq[6 + 2 * j + 1]) for j in range(3))
     vS1 = l6_mul_v(S1)
@@ -646,8 +648,6 @@ def prog_fexp_a(from_wire):
     # n = N0^2 + N1^2
     n1 = b.alloc(1)
     b.mulacc([{"dst": n1[0], "bil": Bil([(Lin.of(ns[0]), Lin.of(ns[0]), 1), (Lin.of(ns[1]), Lin.of(ns[1]), 1)])}])
-    if from_wire:
-        b.gstore(K_STATE, [(f.slots[i], ST_F + i) for i in range(12)])
     b.gstore(K_STATE, [(cs[i], ST_C + i) for i in range(6)] + [(ns[i], ST_NC + i) for i in range(2)] + [(n1[0], ST_N)])
     return b
 
@@ -679,11 +679,10 @@ def cyc_exp(b, a):
 
 
 def prog_fexp_c(to_wire=True):
-    """second half: finish the inversion, easy part, hard part (x-chain), output Gt.  At most four Fp12
-    values are LDS-resident at any time; the rest are spilled to the per-check state buffer."""
+    """second half: finish the inversion, easy part, hard part (x-chain), output Gt.  At most TWO Fp12
+    values are LDS-resident at any time (24 slots => 16 waves per CU); everything else is parked in the
+    per-check state buffer (a spill or fill moves 768 B per check)."""
     b = Builder()
-    f = V12(b.alloc(12))
-    b.gload(K_STATE, [(f.slots[i], ST_F + i) for i in range(12)])
     st = b.alloc(9)
     b.gload(K_STATE, [(st[i], ST_C + i) for i in range(6)] + [(st[6 + i], ST_NC + i) for i in range(2)] + [(st[8], ST_NINV)])
     C = tuple(lin2(st[2 * j], st[2 * j + 1]) for j in range(3))
@@ -693,62 +692,78 @@ def prog_fexp_c(to_wire=True):
     ni = b.alloc(2)
     b.mulacc([{"dst": ni[0], "bil": Bil([(N[0], ninv, 1)])}, {"dst": ni[1], "bil": Bil([(N[1], ninv, -1)])}])
     NI = lin2(ni[0], ni[1])
-    # t^-1 = (C0, C1, C2) * N^-1   (Fp6)
+    # t^-1 = (C0, C1, C2) * N^-1   (Fp6), parked while conj(f)^2 is formed
     ti = b.alloc(6)
     b.mulacc([{"dst": ti[2 * j + c], "bil": b2_mul(C[j], NI)[c]} for j in range(3) for c in range(2)])
-    TI = tuple(lin2(ti[2 * j], ti[2 * j + 1]) for j in range(3))
+    b.gstore(K_STATE, [(ti[i], ST_TI + i) for i in range(6)])
     b.release(st)
     b.release(ni)
-    # f^-1 = (a0 t^-1, -a1 t^-1)
-    finv = b.alloc12()
-    b.mulacc([{"dst": finv.slots[i], "bil": bl} for i, bl in enumerate(flatten12(b6_mul(f.fp6(0), TI), b6_mul(l6_neg(f.fp6(1)), TI)))])
     b.release(ti)
-    # easy part: u = conj(f) * f^-1 ; t2 = frob^2(u) * u
-    u = b.fp12_mul(finv, f.conj(), finv)
-    t2 = b.frobenius(f, u, 2)
+    # f^(p^6-1) = conj(f) / f = conj(f)^2 * t^-1   because f^-1 = conj(f) * t^-1 with t = f conj(f) in Fp6
+    f = V12(b.alloc(12))
+    b.gload(K_STATE, [(f.slots[i], ST_F + i) for i in range(12)])
+    c2 = b.fp12_sqr(f, f.conj())
+    ti = b.alloc(6)
+    b.gload(K_STATE, [(ti[i], ST_TI + i) for i in range(6)])
+    TI = tuple(lin2(ti[2 * j], ti[2 * j + 1]) for j in range(3))
+    u = V12(c2.slots)
+    b.mulacc([{"dst": u.slots[i], "bil": bl} for i, bl in enumerate(flatten12(b6_mul(TI, c2.fp6(0)), b6_mul(TI, c2.fp6(1))))])
+    b.release(ti)
+    # easy part continued: t2 = frob^2(u) * u
+    t2 = b.frobenius(b.alloc(12), u, 2)
     t2 = b.fp12_mul(t2, t2, u)
-    # hard part: the upstream-shaped x-chain of DESIGN.md / SURVEY.md S6 (the products of the last
-    # lines are associated differently to bound LDS residency; exact field arithmetic => same value).
-    # At most three Fp12 values are LDS-resident at any time.
-    t1 = b.cyclotomic_sqr(u, t2).conj()
-    t3 = cyc_exp(b, t2)                          # resident: t1 t2 t3
-    h2 = b.spill(t2, ST_SPILL + 48)
-    t4 = b.cyclotomic_sqr(b.alloc(12), t3)       # t1 t3 t4
-    h4 = b.spill(t4, ST_SPILL + 0)
-    t5 = b.fp12_mul(t1, t1, t3)                  # t1's slots now hold t5 ; t3 t5
-    h3 = b.spill(t3, ST_SPILL + 12)
-    t1 = cyc_exp(b, t5)                          # t5 t1
-    h5 = b.spill(t5, ST_SPILL + 24)
-    t0 = cyc_exp(b, t1)                          # t1 t0
-    h1 = b.spill(t1, ST_SPILL + 36)
-    t6 = cyc_exp(b, t0)                          # t0 t6
-    h0 = b.spill(t0, ST_SPILL + 60)
-    t4 = b.fill(h4)
+    # hard part: the upstream-shaped x-chain of DESIGN.md / SURVEY.md S6 (the products of the last lines
+    # are associated differently to bound LDS residency; exact field arithmetic => same value)
+    SP = [ST_SPILL + 12 * i for i in range(8)]
+    t1 = b.cyclotomic_sqr(u, t2).conj()              # resident: t2 t1
+    h1 = b.spill(t1, SP[0])
+    t3 = cyc_exp(b, t2)                              # t2 t3
+    h2 = b.spill(t2, SP[1])
+    t4 = b.cyclotomic_sqr(b.alloc(12), t3)           # t3 t4
+    h4 = b.spill(t4, SP[2])
+    t1 = b.fill(h1)                                  # t3 t1
+    t5 = b.fp12_mul(t1, t1, t3)                      # t3 t5
+    h3 = b.spill(t3, SP[0])
+    t1 = cyc_exp(b, t5)                              # t5 t1
+    h5 = b.spill(t5, SP[3])
+    t0 = cyc_exp(b, t1)                              # t1 t0
+    h1 = b.spill(t1, SP[4])
+    t6 = cyc_exp(b, t0)                              # t0 t6
+    h0 = b.spill(t0, SP[5])
+    t4 = b.fill(h4)                                  # t6 t4
     t6 = b.fp12_mul(t6, t6, t4)
     b.release(t4.slots)
-    t4 = cyc_exp(b, t6)                          # t6 t4
-    t2 = b.fill(h2)                              # t6 t4 t2
+    t4 = cyc_exp(b, t6)                              # t6 t4
+    h4 = b.spill(t4, SP[2])
+    t2 = b.fill(h2)                                  # t6 t2
     t6 = b.fp12_mul(t6, t6, t2.conj())
     t6 = b.frobenius(t6, t6, 1)
-    h6 = b.spill(t6, ST_SPILL + 0)               # t4 t2
-    t5 = b.fill(h5)                              # t4 t2 t5
+    h6 = b.spill(t6, SP[6])
+    t5 = b.fill(h5)                                  # t2 t5
     t5 = b.fp12_mul(t5, t5.conj(), t2)
+    b.release(t2.slots)
+    t4 = b.fill(h4)                                  # t5 t4
     t4 = b.fp12_mul(t4, t4, t5)
     b.release(t5.slots)
-    t1 = b.fill(h1)                              # t4 t2 t1
+    h4 = b.spill(t4, SP[2])
+    t1 = b.fill(h1)
+    t2 = b.fill(h2)                                  # t1 t2
     t1 = b.fp12_mul(t1, t1, t2)
     b.release(t2.slots)
     t1 = b.frobenius(t1, t1, 3)
+    t4 = b.fill(h4)                                  # t1 t4
     t1 = b.fp12_mul(t1, t1, t4)
-    b.release(t4.slots)                          # t1
-    t6 = b.fill(h6)
+    b.release(t4.slots)
+    t6 = b.fill(h6)                                  # t1 t6
     t1 = b.fp12_mul(t1, t1, t6)
     b.release(t6.slots)
+    h1 = b.spill(t1, SP[4])
     t3 = b.fill(h3)
-    t0 = b.fill(h0)                              # t1 t3 t0
+    t0 = b.fill(h0)                                  # t3 t0
     t3 = b.fp12_mul(t3, t3, t0)
     b.release(t0.slots)
     t3 = b.frobenius(t3, t3, 2)
+    t1 = b.fill(h1)                                  # t3 t1
     t3 = b.fp12_mul(t3, t3, t1)
     b.release(t1.slots)
     finish_output(b, t3, to_wire, ST_F, check_identity=True)
@@ -850,6 +865,14 @@ def canonical_from_reduced(l):
     return v % P
 
 
+def const_limbs(name, val):
+    if name == "RAW_R2":
+        return to_limbs_balanced(RMOD * RMOD % P)
+    if name == "RAW_ONE":
+        return [1] + [0] * (NL - 1)
+    return mont(val)
+
+
 class Emu:
     """one lane-group.  slots hold limb vectors.  `lines`: list of steps, each a list (per pair) of 6
     true field values (c2, c1*xP, c0*yP); `state`/`wire_in`: dict/list of true values."""
@@ -857,9 +880,7 @@ class Emu:
     def __init__(self, lines=None, state=None, wire_in=None):
         self.slot = {}
         for name, val in CONSTS:
-            self.slot[CONST_SLOT[name]] = mont(val)
-        self.slot[CONST_SLOT["RAW_R2"]] = to_limbs_balanced(RMOD * RMOD % P)
-        self.slot[CONST_SLOT["RAW_ONE"]] = [1] + [0] * (NL - 1)
+            self.slot[CONST_SLOT[name]] = const_limbs(name, val)
         self.lines = lines or []
         self.cursor = 0
         self.state = dict(state or {})     # element -> limb vector
@@ -1111,11 +1132,7 @@ def write_inc(path):
              "#define ZKP_COOP_VRED_SHIFT_OUT %d" % VRED_SHIFT_OUT,
              "#define ZKP_COOP_P_BAL %s" % ", ".join(str(x) for x in P_BAL)]
     # constants region: Montgomery limbs (balanced), 16 dwords per constant
-    rows = []
-    for name, val in CONSTS:
-        rows.append(mont(val))
-    rows.append(to_limbs_balanced(RMOD * RMOD % P))
-    rows.append([1] + [0] * (NL - 1))
+    rows = [const_limbs(name, val) for name, val in CONSTS]
     lines.append("static const int32_t ZKP_COOP_CONSTS[%d][16] = {" % N_CONST)
     for r in rows:
         lines.append("  {" + ", ".join(str(x) for x in r + [0, 0]) + "},")
@@ -1128,11 +1145,22 @@ def write_inc(path):
         hdr, tbl = encode(b)
         lines.append("static const uint32_t ZKP_PROG_%s_HDR[%d] = {%s};" % (n.upper(), len(hdr), ",".join(str(x) for x in hdr)))
         lines.append("static const uint32_t ZKP_PROG_%s_TBL[%d] = {%s};" % (n.upper(), max(1, len(tbl)), ",".join(str(x) for x in tbl) if tbl else "0"))
-        meta.append((n, len(hdr), len(tbl), b.peak))
-    lines.append("struct ZkpProgDesc { const uint32_t* hdr; uint32_t n_hdr; const uint32_t* tbl; uint32_t n_tbl; uint32_t nslot; };")
+        used = [CONST_BASE]
+        for st in b.steps:
+            if st["op"] == OP_MULACC:
+                for ln in st["lanes"]:
+                    for tm in ln["terms"]:
+                        used += [tm[0], tm[1], tm[3], tm[4]]
+                    used.append(ln["e"])
+            elif st["op"] == OP_LIN:
+                for _, terms in st["lanes"]:
+                    used += [sl for sl, _ in terms]
+        nconst = max(x for x in used if x >= CONST_BASE) - CONST_BASE + 1
+        meta.append((n, len(hdr), len(tbl), b.peak, nconst))
+    lines.append("struct ZkpProgDesc { const uint32_t* hdr; uint32_t n_hdr; const uint32_t* tbl; uint32_t n_tbl; uint32_t nslot; uint32_t nconst; };")
     lines.append("static const ZkpProgDesc ZKP_PROGS[ZKP_PROG_COUNT] = {")
-    for n, nh, nt, peak in meta:
-        lines.append("  {ZKP_PROG_%s_HDR, %d, ZKP_PROG_%s_TBL, %d, %d}," % (n.upper(), nh, n.upper(), max(1, nt), peak))
+    for n, nh, nt, peak, nconst in meta:
+        lines.append("  {ZKP_PROG_%s_HDR, %d, ZKP_PROG_%s_TBL, %d, %d, %d}," % (n.upper(), nh, n.upper(), max(1, nt), peak, nconst))
     lines.append("};")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
@@ -1141,6 +1169,6 @@ def write_inc(path):
 
 if __name__ == "__main__":
     out = os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_coop_prog.inc")
-    for n, nh, nt, peak in write_inc(out):
-        print("%-16s steps=%4d table_words=%6d peak_slots=%d" % (n, nh // 4, nt, peak))
+    for n, nh, nt, peak, nconst in write_inc(out):
+        print("%-16s steps=%4d table_words=%6d peak_slots=%d consts=%d" % (n, nh // 4, nt, peak, nconst))
     print("wrote", out)

@@ -31,7 +31,6 @@ namespace {
 
 constexpr int GROUPS = 5;              // checks per wavefront
 constexpr int LIG = ZKP_COOP_G;        // 12 lanes per group
-constexpr int NCONST = ZKP_COOP_NCONST;
 constexpr int ST_SIZE = ZKP_COOP_ST_SIZE;
 constexpr int NLINES = ZKP_COOP_NLINES;
 
@@ -54,6 +53,7 @@ struct CoopArgs {
     uint32_t nc;              // record stride (>= n_checks)
     uint32_t k;
     uint32_t S;               // LDS plane stride (int4) of a group region (= the program's slot count)
+    uint32_t nconst;          // constants the program references (prefix of the table)
 };
 
 // ---- LDS access: quad-plane SoA, record = 4 x int4 at off, off+S, off+2S, off+3S
@@ -108,7 +108,10 @@ __device__ __forceinline__ void canon28(uint32_t* f, const int32_t* x) {
     for (int i = 0; i < NL; i++) f[i] = (uint32_t)(neg ? z[i] : (ge ? y[i] : u[i]));
 }
 
-__global__ void __launch_bounds__(64) k_coop(CoopArgs A) {
+#ifndef ZKP_COOP_WAVES
+#define ZKP_COOP_WAVES 4   // 128 VGPRs; with 24-slot programs 16 waves fit a CU (LDS 8-10 KB per wave)
+#endif
+__global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     extern __shared__ int4 lds[];
     const int lane = threadIdx.x;
     const int grp = (lane * 43) >> 9;          // lane / 12 for lane < 64
@@ -117,11 +120,11 @@ __global__ void __launch_bounds__(64) k_coop(CoopArgs A) {
     const uint32_t check = blockIdx.x * GROUPS + grp;
     const bool active = lane_ok && check < A.n_checks;
     const int S = (int)A.S;
-    constexpr int SC = NCONST;                 // plane stride of the constants region
+    const int SC = (int)A.nconst;              // plane stride of the constants region
     const int cbase = 0;
     const int gbase = 4 * SC + (lane_ok ? grp : GROUPS - 1) * (4 * S + 3);
 
-    for (int i = lane; i < NCONST * 4; i += 64) lds[(i & 3) * SC + (i >> 2)] = A.consts[i];
+    for (int i = lane; i < SC * 4; i += 64) lds[(i & 3) * SC + (i >> 2)] = A.consts[i];
     __syncthreads();
 
     const uint32_t* __restrict__ hdr = A.hdr;
@@ -147,11 +150,11 @@ __global__ void __launch_bounds__(64) k_coop(CoopArgs A) {
             uint32_t w = tbl[off + lig];
             uint32_t wn = T > 1 ? tbl[off + LIG + lig] : 0;
             const uint32_t ew = tbl[off + T * LIG + lig];
-            int32_t xa[NL], xa2[NL], xb[NL], xb2[NL];
+            // primary operands are prefetched one term ahead; the (rarer) second operands are fetched at
+            // the top of their term - this keeps the kernel at 128 VGPRs = 4 waves per SIMD
+            int32_t xa[NL], xb[NL];
             ld(xa, w & 127);
-            if (!(h3 & 1)) ld(xa2, (w >> 7) & 127);
             ld(xb, (w >> 14) & 127);
-            if (!((h3 >> 12) & 1)) ld(xb2, (w >> 21) & 127);
 #pragma unroll 1
             for (uint32_t t = 0; t < T; t++) {
                 const bool no_a2 = (h3 >> t) & 1, no_b2 = (h3 >> (12 + t)) & 1;   // wave-uniform
@@ -161,23 +164,25 @@ __global__ void __launch_bounds__(64) k_coop(CoopArgs A) {
 #pragma unroll
                     for (int i = 0; i < NL; i++) a[i] = (xa[i] ^ mn) - mn;
                 } else {
+                    int32_t x2[NL];
+                    ld(x2, (w >> 7) & 127);
 #pragma unroll
-                    for (int i = 0; i < NL; i++) a[i] = ((xa[i] + ((xa2[i] ^ ma) - ma)) ^ mn) - mn;
+                    for (int i = 0; i < NL; i++) a[i] = ((xa[i] + ((x2[i] ^ ma) - ma)) ^ mn) - mn;
                 }
                 if (no_b2) {
 #pragma unroll
                     for (int i = 0; i < NL; i++) b[i] = xb[i];
                 } else {
+                    int32_t x2[NL];
+                    ld(x2, (w >> 21) & 127);
 #pragma unroll
-                    for (int i = 0; i < NL; i++) b[i] = xb[i] + ((xb2[i] ^ mb) - mb);
+                    for (int i = 0; i < NL; i++) b[i] = xb[i] + ((x2[i] ^ mb) - mb);
                 }
                 if (t + 1 < T) {
                     w = wn;
                     if (t + 2 < T) wn = tbl[off + (t + 2) * LIG + lig];
                     ld(xa, w & 127);
-                    if (!((h3 >> (t + 1)) & 1)) ld(xa2, (w >> 7) & 127);
                     ld(xb, (w >> 14) & 127);
-                    if (!((h3 >> (13 + t)) & 1)) ld(xb2, (w >> 21) & 127);
                 }
                 acc_mul(acc, a, b);
             }
@@ -538,7 +543,7 @@ __global__ void k_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint6
 // =============================================================================== host side
 namespace zkp {
 
-struct CoopProgDev { uint32_t* hdr; uint32_t* tbl; uint32_t nslot; };
+struct CoopProgDev { uint32_t* hdr; uint32_t* tbl; uint32_t nslot; uint32_t nconst; };
 constexpr int MAX_PIPES = 4;
 struct CoopPipe {            // one in-flight chunk: its own workspace and (for pipes > 0) its own stream
     int4* lines;  size_t lines_bytes;
@@ -567,6 +572,7 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
         if ((e = hipMemcpy(d->progs[i].hdr, p.hdr, p.n_hdr * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
         if ((e = hipMemcpy(d->progs[i].tbl, p.tbl, p.n_tbl * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
         d->progs[i].nslot = p.nslot;
+        d->progs[i].nconst = p.nconst;
     }
     if ((e = hipMalloc((void**)&d->consts, sizeof(ZKP_COOP_CONSTS))) != hipSuccess) return e;
     if ((e = hipMemcpy(d->consts, ZKP_COOP_CONSTS, sizeof(ZKP_COOP_CONSTS), hipMemcpyHostToDevice)) != hipSuccess) return e;
@@ -638,7 +644,10 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     a.k = k;
     uint32_t S = d->progs[prog].nslot;
     a.S = S;
-    size_t lds_bytes = (size_t)(4 * NCONST + GROUPS * (4 * S + 3)) * 16;
+    a.nconst = d->progs[prog].nconst;
+    size_t lds_bytes = (size_t)(4 * a.nconst + GROUPS * (4 * S + 3)) * 16;
+    static const char* pad_env = getenv("ZKP_COOP_LDS_PAD");   // occupancy experiments only
+    if (pad_env) lds_bytes += (size_t)atol(pad_env);
     unsigned blocks = (n_checks + GROUPS - 1) / GROUPS;
     hipLaunchKernelGGL(k_coop, dim3(blocks), dim3(64), lds_bytes, s, a);
     return hipGetLastError();
