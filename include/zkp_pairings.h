@@ -96,6 +96,18 @@ int zkp_g1_mul_batch(zkp_ctx* ctx, const uint64_t* base, size_t base_stride, con
                      uint64_t* out, uint8_t* out_inf);
 int zkp_g2_mul_batch(zkp_ctx* ctx, const uint64_t* base, size_t base_stride, const uint64_t* scalars, size_t n,
                      uint64_t* out, uint8_t* out_inf);
+/* ---- uncompressed point byte codec (big-endian field elements, reference src/fp.rs:165-207 with the range
+ * check done CORRECTLY - upstream's Fp::from_bytes accepts exactly the non-canonical values).
+ * G1: x(48) | y(48) = 96 bytes; G2: x.c1 | x.c0 | y.c1 | y.c0 = 192 bytes (c1 first, the usual BLS12-381
+ * serialisation order).  The top three bits of byte 0 are flags: 0x80 compressed (rejected), 0x40 infinity
+ * (all other bytes must be zero), 0x20 must be clear.
+ * status[i]: 0 ok, 1 coordinate >= p, 2 bad flags / malformed infinity.  Decoded points go out in wire
+ * format (+ infinity byte) and can be fed to zkp_g*_is_valid_batch / zkp_pairing_*. */
+int zkp_g1_decode_batch(zkp_ctx* ctx, const uint8_t* bytes, size_t n, uint64_t* out_g1, uint8_t* out_inf, uint8_t* status);
+int zkp_g2_decode_batch(zkp_ctx* ctx, const uint8_t* bytes, size_t n, uint64_t* out_g2, uint8_t* out_inf, uint8_t* status);
+int zkp_g1_encode_batch(zkp_ctx* ctx, const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* out_bytes);
+int zkp_g2_encode_batch(zkp_ctx* ctx, const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* out_bytes);
+
 /* batched field op in the zkVM precompile shape: op 0 = mul, 1 = add (src/fp.rs:376,443) */
 int zkp_fp_op_batch(zkp_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
 

@@ -303,6 +303,44 @@ def test_device_tensor_api_matches_host_api(keng):
     assert torch.equal(out, gt) and flag.item() == 0
 
 
+def test_byte_codec_and_config5_flow(eng):
+    """uncompressed big-endian codec (correct range check; upstream's Fp::from_bytes is inverted, src/fp.rs:165-191)
+    and the config-5 flow: raw bytes -> decode -> on-curve + subgroup check -> pairing check."""
+    from zkvm_pairings_amd import synthetic
+    n = 64
+    g1, g2, a, b = synthetic.random_pairs(eng, n, seed=2024)
+    raw1, raw2 = eng.encode_points(g1, 1), eng.encode_points(g2, 2)
+    # independent expectation: big-endian field elements, G2 with c1 first
+    for j in (0, 17, 63):
+        x, y = o.from_limbs(g1[j, :6]), o.from_limbs(g1[j, 6:])
+        assert raw1[96 * j:96 * j + 96] == x.to_bytes(48, "big") + y.to_bytes(48, "big")
+        assert raw1[96 * j:96 * j + 48] == o.fp_to_bytes_be(g1[j, :6])
+        c = [o.from_limbs(g2[j, 6 * e:6 * e + 6]) for e in range(4)]
+        assert raw2[192 * j:192 * j + 192] == b"".join(v.to_bytes(48, "big") for v in (c[1], c[0], c[3], c[2]))
+    d1, i1, s1 = eng.decode_points(raw1, 1)
+    d2, i2, s2 = eng.decode_points(raw2, 2)
+    assert np.array_equal(d1, g1) and np.array_equal(d2, g2) and not i1.any() and not i2.any() and not s1.any() and not s2.any()
+    # malformed inputs: x = p (non canonical), compressed flag, infinity with garbage, proper infinity
+    bad = bytearray(raw1[:96 * 4])
+    bad[0:48] = m.P.to_bytes(48, "big")
+    bad[96] |= 0x80
+    bad[192] = 0x40
+    bad[192 + 5] = 1
+    bad[288:384] = bytes([0x40]) + bytes(95)
+    pts, inf, st = eng.decode_points(bytes(bad), 1)
+    assert st.tolist() == [1, 2, 2, 0] and inf.tolist() == [0, 0, 0, 1]
+    assert eng.encode_points(pts[3:4], 1, inf[3:4]) == bytes(bad[288:384])
+    assert (m.P - 1).to_bytes(48, "big") + bytes(48) == eng.encode_points(np.concatenate([o.to_limbs(m.P - 1), o.to_limbs(0)]), 1)
+    # config-5 flow on e(aP, bQ) e(-abP, Q) == 1 pairs built from the decoded points
+    assert not eng.g1_is_valid(d1, i1).any() and not eng.g2_is_valid(d2, i2).any()
+    ab = np.stack([synthetic.int_to_scalar((-synthetic.scalar_to_int(x) * synthetic.scalar_to_int(y)) % m.R_ORDER) for x, y in zip(a, b)])
+    p3, _ = eng.g1_mul(synthetic.G1_GENERATOR, ab)
+    G1 = np.stack([d1, p3], axis=1).reshape(2 * n, 12)
+    G2 = np.stack([d2, np.tile(synthetic.G2_GENERATOR, (n, 1))], axis=1).reshape(2 * n, 24)
+    ok, allok = eng.pairing_check(G1, G2, 2)
+    assert ok.all() and allok
+
+
 def test_validation_mode_rejects_noncanonical(eng):
     from zkvm_pairings_amd import _lib, synthetic
     bad = synthetic.G1_GENERATOR.copy()

@@ -33,6 +33,10 @@ SIGNATURES = {
     "zkp_g2_is_valid_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "zkp_g1_mul_batch": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp, c_vp]),
     "zkp_g2_mul_batch": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp, c_vp]),
+    "zkp_g1_decode_batch": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "zkp_g2_decode_batch": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "zkp_g1_encode_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "zkp_g2_encode_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "zkp_fp_op_batch": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
     "zkp_pairing_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp]),
     "zkp_multi_miller_loop_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, c_vp]),

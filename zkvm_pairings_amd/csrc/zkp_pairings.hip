@@ -217,6 +217,52 @@ __global__ void k_fp_op(int op, const uint64_t* a, const uint64_t* b, size_t n, 
     fp_store(out + 6 * i, &r);
 }
 
+// ---- uncompressed byte codec: nfp big-endian 48-byte field elements per point (2 for G1, 4 for G2).
+// G2 stores c1 before c0, so element e of the byte string is wire element (e ^ 1) when nfp == 4.
+__global__ void k_decode(const uint8_t* bytes, size_t n, int nfp, uint64_t* out, uint8_t* out_inf, uint8_t* status) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* src = bytes + i * 48 * nfp;
+    const uint8_t flags = src[0] & 0xe0;
+    uint8_t st = 0, inf = 0;
+    if (flags & 0xa0) st = 2;                       // compressed or sort flag: not an uncompressed point
+    if (!st && (flags & 0x40)) {
+        inf = 1;
+        uint8_t any = src[0] & 0x1f;
+        for (int b = 1; b < 48 * nfp; b++) any |= src[b];
+        if (any) st = 2;
+    }
+    for (int e = 0; e < nfp; e++) {
+        uint64_t limbs[6];
+        for (int w = 0; w < 6; w++) {
+            uint64_t v = 0;
+            for (int b = 0; b < 8; b++) v = (v << 8) | src[48 * e + 8 * w + b];
+            if (e == 0 && w == 0) v &= 0x1fffffffffffffffULL;   // strip the flag bits
+            limbs[5 - w] = v;
+        }
+        if (!st && !inf && !fp_wire_is_canonical(limbs)) st = 1;
+        const int we = nfp == 4 ? (e ^ 1) : e;
+        for (int w = 0; w < 6; w++) out[(i * nfp + we) * 6 + w] = (st || inf) ? 0 : limbs[w];
+    }
+    if (inf && !st) out[(i * nfp + nfp / 2) * 6] = 1;   // identity is (0, 1) like the reference (src/g1.rs:25-31)
+    out_inf[i] = inf && !st;
+    status[i] = st;
+}
+__global__ void k_encode(const uint64_t* pts, const uint8_t* inf, size_t n, int nfp, uint8_t* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t* dst = out + i * 48 * nfp;
+    const bool is_inf = inf && inf[i];
+    for (int e = 0; e < nfp; e++) {
+        const int we = nfp == 4 ? (e ^ 1) : e;
+        for (int w = 0; w < 6; w++) {
+            uint64_t v = is_inf ? 0 : pts[(i * nfp + we) * 6 + (5 - w)];
+            for (int b = 0; b < 8; b++) dst[48 * e + 8 * w + b] = (uint8_t)(v >> (56 - 8 * b));
+        }
+    }
+    if (is_inf) dst[0] |= 0x40;
+}
+
 // every 6-limb element of a wire buffer must be < p
 __global__ void k_check_canonical(const uint64_t* a, size_t n_fp, int* bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -599,6 +645,47 @@ int zkp_g1_mul_batch(zkp_ctx* c, const uint64_t* base, size_t stride, const uint
 int zkp_g2_mul_batch(zkp_ctx* c, const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf) {
     return mul_host(c, 2, base, stride, sc, n, out, out_inf);
 }
+static int codec_host(zkp_ctx* c, bool decode, int nfp, const void* in, const uint8_t* inf_in, size_t n, void* out, uint8_t* out_inf, uint8_t* status) {
+    if (!c || (n && (!in || !out)) || (decode && n && (!out_inf || !status))) return ZKP_ERR_ARG;
+    if (!n) return ZKP_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    const size_t nb = n * 48 * nfp;
+    if ((rc = ensure(c, 0, nb)) || (rc = ensure(c, 4, nb)) || (rc = ensure(c, 2, n)) || (rc = ensure(c, 6, n))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->buf[0], in, nb, hipMemcpyHostToDevice, c->stream));
+    if (decode) {
+        hipLaunchKernelGGL(k_decode, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const uint8_t*)c->buf[0], n, nfp, (uint64_t*)c->buf[4],
+                           (uint8_t*)c->buf[2], (uint8_t*)c->buf[6]);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(out, c->buf[4], nb, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_inf, c->buf[2], n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(status, c->buf[6], n, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        const uint8_t* di = nullptr;
+        if (inf_in) {
+            HIPCHK(c, hipMemcpyAsync(c->buf[2], inf_in, n, hipMemcpyHostToDevice, c->stream));
+            di = (const uint8_t*)c->buf[2];
+        }
+        hipLaunchKernelGGL(k_encode, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const uint64_t*)c->buf[0], di, n, nfp, (uint8_t*)c->buf[4]);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(out, c->buf[4], nb, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZKP_OK;
+}
+int zkp_g1_decode_batch(zkp_ctx* c, const uint8_t* bytes, size_t n, uint64_t* out, uint8_t* out_inf, uint8_t* status) {
+    return codec_host(c, true, 2, bytes, nullptr, n, out, out_inf, status);
+}
+int zkp_g2_decode_batch(zkp_ctx* c, const uint8_t* bytes, size_t n, uint64_t* out, uint8_t* out_inf, uint8_t* status) {
+    return codec_host(c, true, 4, bytes, nullptr, n, out, out_inf, status);
+}
+int zkp_g1_encode_batch(zkp_ctx* c, const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* out) {
+    return codec_host(c, false, 2, g1, inf, n, out, nullptr, nullptr);
+}
+int zkp_g2_encode_batch(zkp_ctx* c, const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* out) {
+    return codec_host(c, false, 4, g2, inf, n, out, nullptr, nullptr);
+}
+
 int zkp_fp_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
     if (!c || (op != 0 && op != 1 && op != 2) || (n && (!a || !b || !out))) return ZKP_ERR_ARG;
     if (!n) return ZKP_OK;

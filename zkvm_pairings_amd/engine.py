@@ -168,6 +168,28 @@ class PairingEngine:
         self._chk(self._lib.zkp_g2_mul_batch(self._h, _ptr(base), stride, _ptr(sc), n, _ptr(out), _ptr(oi)))
         return out, oi
 
+    def decode_points(self, data, which):
+        """uncompressed big-endian bytes -> (points, inf, status); which = 1 (G1, 96 B) or 2 (G2, 192 B)"""
+        size = 96 if which == 1 else 192
+        buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        assert buf.size % size == 0
+        n = buf.size // size
+        pts = np.empty((n, size // 8), dtype=np.uint64)
+        inf, st = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8)
+        fn = self._lib.zkp_g1_decode_batch if which == 1 else self._lib.zkp_g2_decode_batch
+        self._chk(fn(self._h, _ptr(buf), n, _ptr(pts), _ptr(inf), _ptr(st)))
+        return pts, inf, st
+
+    def encode_points(self, pts, which, inf=None):
+        cols = 12 if which == 1 else 24
+        pts = _np(pts, cols)
+        n = pts.shape[0]
+        i = None if inf is None else _np(inf, None, np.uint8)
+        out = np.empty(n * cols * 8, dtype=np.uint8)
+        fn = self._lib.zkp_g1_encode_batch if which == 1 else self._lib.zkp_g2_encode_batch
+        self._chk(fn(self._h, _ptr(pts), _ptr(i), n, _ptr(out)))
+        return out.tobytes()
+
     def fp_op(self, op, a, b):
         """zkVM-precompile-shaped batched field op: op 0 = mul, 1 = add (reference src/fp.rs:376,443)."""
         a, b = _np(a, 6), _np(b, 6)
