@@ -50,6 +50,7 @@ def _balanced(v):
 P_BAL = _balanced(P)                      # balanced limbs of p (|limb| <= 2^27), used by the value renormalisation
 VRED_SHIFT_IN, VRED_SHIFT_OUT = 9, 24
 VRED_C = round((1 << (VRED_SHIFT_IN + VRED_SHIFT_OUT)) / P_BAL[NL - 1])
+LDS_SLOTS = 24         # slots every program must fit: 16 wavefronts of 5 groups share a CU's 160 KB of LDS
 G = 12                 # lanes per group
 NSLOT = 64             # group-local slots are 0..NSLOT-1; constants are NSLOT..127
 CONST_BASE = 64
@@ -1124,7 +1125,7 @@ PROGRAMS = {
 def write_inc(path):
     lines = ["// GENERATED by tools/coopgen.py - do not edit.  Step programs of the lane-cooperative kernels.",
              "#pragma once", "#include <stdint.h>",
-             "#define ZKP_COOP_G %d" % G, "#define ZKP_COOP_NSLOT_MAX %d" % NSLOT,
+             "#define ZKP_COOP_G %d" % G, "#define ZKP_COOP_NSLOT_MAX %d" % NSLOT, "#define ZKP_COOP_NSLOT %d" % LDS_SLOTS,
              "#define ZKP_COOP_NCONST %d" % N_CONST, "#define ZKP_COOP_ST_SIZE %d" % ST_SIZE,
              "#define ZKP_COOP_ST_N %d" % ST_N, "#define ZKP_COOP_ST_NINV %d" % ST_NINV,
              "#define ZKP_COOP_NLINES %d" % n_line_steps(),

@@ -119,12 +119,13 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     const bool lane_ok = grp < GROUPS;
     const uint32_t check = blockIdx.x * GROUPS + grp;
     const bool active = lane_ok && check < A.n_checks;
-    const int S = (int)A.S;
-    const int SC = (int)A.nconst;              // plane stride of the constants region
+    // compile-time plane strides: the q * stride offsets fold into the ds_read/ds_write immediates
+    constexpr int S = ZKP_COOP_NSLOT;          // every generated program fits this many slots
+    constexpr int SC = ZKP_COOP_NCONST;        // plane stride of the constants region (A.nconst of them are uploaded)
     const int cbase = 0;
     const int gbase = 4 * SC + (lane_ok ? grp : GROUPS - 1) * (4 * S + 3);
 
-    for (int i = lane; i < SC * 4; i += 64) lds[(i & 3) * SC + (i >> 2)] = A.consts[i];
+    for (int i = lane; i < (int)A.nconst * 4; i += 64) lds[(i & 3) * SC + (i >> 2)] = A.consts[i];
     __syncthreads();
 
     const uint32_t* __restrict__ hdr = A.hdr;
@@ -642,10 +643,10 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     a.n_checks = n_checks;
     a.nc = nc;
     a.k = k;
-    uint32_t S = d->progs[prog].nslot;
-    a.S = S;
+    if (d->progs[prog].nslot > (uint32_t)ZKP_COOP_NSLOT) return hipErrorInvalidValue;
+    a.S = ZKP_COOP_NSLOT;
     a.nconst = d->progs[prog].nconst;
-    size_t lds_bytes = (size_t)(4 * a.nconst + GROUPS * (4 * S + 3)) * 16;
+    size_t lds_bytes = (size_t)(4 * ZKP_COOP_NCONST + GROUPS * (4 * ZKP_COOP_NSLOT + 3)) * 16;
     static const char* pad_env = getenv("ZKP_COOP_LDS_PAD");   // occupancy experiments only
     if (pad_env) lds_bytes += (size_t)atol(pad_env);
     unsigned blocks = (n_checks + GROUPS - 1) / GROUPS;
