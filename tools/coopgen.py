@@ -371,7 +371,17 @@ class Builder:
             for a, b in terms:
                 ea, eb = encode_form(a), encode_form(b)
                 assert ea and eb
-                enc.append((ea[0], ea[1], ea[2], eb[0], eb[1], eb[2], bool(ea[3]) ^ bool(eb[3])))
+                a1, a2, asub, b1, b2, bsub = ea[0], ea[1], ea[2], eb[0], eb[1], eb[2]
+                neg = bool(ea[3]) ^ bool(eb[3])
+                # a sign is free when a form is a difference: -(x - y) = (y - x)
+                if neg and asub:
+                    a1, a2, neg = a2, a1, False
+                elif neg and bsub:
+                    b1, b2, neg = b2, b1, False
+                enc.append((a1, a2, asub, b1, b2, bsub, neg))
+            # order every lane's terms alike (plain terms first, negated / two-slot ones last) so that more term
+            # positions are uniformly free of negations and second operands across the 12 lanes
+            enc.sort(key=lambda x: (bool(x[6]), x[1] != ZERO, x[4] != ZERO))
             lanes.append({"dst": o["dst"], "terms": enc, "alpha": o.get("alpha", 1), "beta": o.get("beta", 0), "e": o.get("e", ZERO)})
         T = max(len(l["terms"]) for l in lanes)
         assert T >= 1
@@ -1035,7 +1045,11 @@ def encode(builder):
                     no_a2 |= 1 << t
                 if all(x[4] == ZERO and not x[5] for x in ts_):
                     no_b2 |= 1 << t
-            hdr += [op | (T << 8), int(st["epi"]), off, no_a2 | (no_b2 << 12)]
+            no_neg = 0
+            for t in range(T):
+                if not any(ln["terms"][t][6] for ln in st["lanes"] if t < len(ln["terms"])):
+                    no_neg |= 1 << t
+            hdr += [op | (T << 8), int(st["epi"]) | (no_neg << 4), off, no_a2 | (no_b2 << 12)]
         elif op == OP_LIN:
             nt = st["nt"]
             for t in range(nt):

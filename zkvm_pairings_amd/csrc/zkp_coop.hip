@@ -159,9 +159,13 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
 #pragma unroll 1
             for (uint32_t t = 0; t < T; t++) {
                 const bool no_a2 = (h3 >> t) & 1, no_b2 = (h3 >> (12 + t)) & 1;   // wave-uniform
+                const bool no_neg = (h1 >> (4 + t)) & 1;                          // no lane negates this term
                 const int32_t ma = -(int32_t)((w >> 28) & 1), mb = -(int32_t)((w >> 29) & 1), mn = -(int32_t)((w >> 30) & 1);
                 int32_t a[NL], b[NL];
-                if (no_a2) {
+                if (no_a2 && no_neg) {
+#pragma unroll
+                    for (int i = 0; i < NL; i++) a[i] = xa[i];
+                } else if (no_a2) {
 #pragma unroll
                     for (int i = 0; i < NL; i++) a[i] = (xa[i] ^ mn) - mn;
                 } else {
