@@ -235,6 +235,30 @@ def test_config2_full_batch_bit_exact(eng):
     assert ok.all() and allok
 
 
+def test_chunk_and_group_boundaries(monkeypatch):
+    """sizes around the 5-checks-per-wavefront and chunk boundaries, with the pipeline forced to many small
+    chunks over several streams (ZKP_COOP_CHUNK / ZKP_COOP_STREAMS are read at zkp_init)."""
+    from zkvm_pairings_amd import PairingEngine, synthetic
+    monkeypatch.setenv("ZKP_COOP_CHUNK", "320")
+    monkeypatch.setenv("ZKP_COOP_STREAMS", "3")
+    e = PairingEngine(0)
+    try:
+        g1, g2, _, _ = synthetic.random_pairs(e, 1003, seed=99)
+        inf1 = np.zeros(1003, dtype=np.uint8)
+        inf1[[0, 319, 320, 641, 1002]] = 1
+        want = o.pairing_batch(g1, g2, inf1, None, NTHREADS)
+        assert np.array_equal(e.pairing(g1, g2, inf1, None), want)        # 4 chunks over 3 pipelines
+        for n in (1, 4, 5, 6, 59, 60, 61, 64, 65, 319, 320, 321, 640, 641):
+            assert np.array_equal(e.pairing(g1[:n], g2[:n], inf1[:n], None), want[:n]), n
+        ml = e.multi_miller_loop(g1[:999], g2[:999], 3, inf1[:999], None)       # 333 checks of 3 pairs, 2 chunks
+        assert np.array_equal(ml, o.multi_miller_loop_batch(g1[:999], g2[:999], 333, 3, inf1[:999], None))
+        assert np.array_equal(e.final_exponentiation(ml), o.final_exponentiation_batch(ml))
+        ok, allok = e.pairing_check(g1[:1000], g2[:1000], 2, inf1[:1000], None)
+        assert np.array_equal(ok, o.pairing_check_batch(g1[:1000], g2[:1000], 500, 2, inf1[:1000], None)) and not allok
+    finally:
+        e.close()
+
+
 def test_final_exponentiation_of_arbitrary_fp12(keng):
     """final_exponentiation must agree with the oracle on ANY invertible Fp12 (not only Miller outputs),
     including 1, -1, elements of Fp / Fp2 / Fp6 embedded in Fp12 and limbs at the top of the range."""
