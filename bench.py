@@ -66,6 +66,11 @@ def main():
         eng.pairing_gt_check(g1, g2, 1, out_gt, ok, flag)
         zdist.and_reduce(flag)  # AND of {0,1} flags == MIN; the only collective on the path
 
+    if world > 1:
+        # establish the RCCL communicator outside the timed region even when --warmup 0 is requested
+        probe = torch.ones(1, dtype=torch.int32, device=dev)
+        zdist.and_reduce(probe)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     if world > 1:
