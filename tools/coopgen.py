@@ -302,10 +302,20 @@ def encode_form(f):
 
 # ------------------------------------------------------------------------------------------ program builder
 class Builder:
+    K_REDUCED = 1.05      # |value| / p after a Montgomery reduction of a budget-respecting accumulation
+    K_VRED = 0.51         # after the value renormalisation
+    K_INPUT = 1.1         # anything a program hands to another through the state buffer (asserted at the store;
+                          # spills inside a program keep their own bound)
+    K_MAX = 8.0           # LIN results above this get the renormalisation
+
     def __init__(self):
         self.steps = []
         self.free = list(range(NSLOT - 1, -1, -1))
         self.peak = 0
+        self.K = {}           # static worst-case |value|/p per group-local slot
+
+    def kof(self, slot):
+        return 1.0 if slot >= CONST_BASE else self.K.get(slot, self.K_INPUT)
 
     # ---- slots
     def alloc(self, n=1):
@@ -329,11 +339,17 @@ class Builder:
         nt = max(len(f) for _, f in lanes)
         assert 1 <= nt <= 4, nt
         ent = []
+        kout = []
         for dst, f in lanes:
             terms = sorted(f.items())
             assert all(-8 <= c <= 8 and c != 0 for _, c in terms)
             ent.append((dst, terms))
-        self.steps.append({"op": OP_LIN, "nt": nt, "lanes": ent})
+            kout.append(sum(abs(c) * self.kof(s) for s, c in terms))
+        vred_needed = max(kout) > self.K_MAX
+        assert max(kout) < 14, "LIN result too large even for the renormalisation"
+        for (dst, _), k in zip(ent, kout):
+            self.K[dst] = self.K_VRED if vred_needed else k
+        self.steps.append({"op": OP_LIN, "nt": nt, "lanes": ent, "vred": vred_needed})
 
     def mulacc(self, outs):
         """outs: list (<=12) of dict(dst=slot, bil=Bil or list of (Lin,Lin) merged, alpha=1, beta=0, e=ZERO).
@@ -397,16 +413,32 @@ class Builder:
             assert budget <= 30, "column budget exceeded: %d" % budget
         epi = [(l["alpha"], l["beta"]) != (1, 0) for l in lanes]
         assert all(epi) or not any(epi), "epilogue must be step-uniform"
+        # value bounds: sum_t Ka*Kb / 2^11 + 1 must stay small; two-slot forms add their slots' bounds
+        for l in lanes:
+            tot = 0.0
+            for (a1, a2, asub, b1, b2, bsub, neg) in l["terms"]:
+                ka = self.kof(a1) + (self.kof(a2) if a2 != ZERO else 0)
+                kb = self.kof(b1) + (self.kof(b2) if b2 != ZERO else 0)
+                tot += ka * kb
+            assert tot / 2048 + 1 <= 1.3, "value budget exceeded: %.1f" % tot
+            if epi[0]:
+                assert abs(l["alpha"]) * 1.3 + abs(l["beta"]) * self.kof(l["e"]) < 14
+        for l in lanes:
+            self.K[l["dst"]] = self.K_VRED if epi[0] else self.K_REDUCED
         self.steps.append({"op": OP_MULACC, "T": T, "lanes": lanes, "epi": bool(epi[0])})
         self.release(list(temps.values()))
         return T
 
-    def gload(self, kind, lanes, advance=0):
+    def gload(self, kind, lanes, advance=0, kbound=None):
         """lanes: list of (dst, index).  K_LINE: index = coefficient (0..5) of pair `pair` at the stream
         cursor; K_STATE: index = state element; K_WIRE: index = Fp index in the wire record."""
+        for dst, _ in lanes:
+            self.K[dst] = kbound if kbound is not None else (self.K_REDUCED if kind != K_STATE else self.K_INPUT)
         self.steps.append({"op": OP_GLOAD, "kind": kind, "lanes": list(lanes), "advance": advance})
 
-    def gstore(self, kind, lanes, check_identity=False):
+    def gstore(self, kind, lanes, check_identity=False, spill=False):
+        if kind == K_STATE and not spill:
+            assert all(self.kof(s) <= self.K_INPUT for s, _ in lanes), "inter-program state must be reduced values"
         self.steps.append({"op": OP_GSTORE, "kind": kind, "lanes": list(lanes), "check": check_identity})
 
     def loop(self, n):
@@ -516,14 +548,15 @@ class Builder:
 
     # ---- spills to the per-check state buffer (12 elements starting at `elem`)
     def spill(self, v, elem):
-        self.gstore(K_STATE, [(v.slots[i], elem + i) for i in range(12)])
+        self.gstore(K_STATE, [(v.slots[i], elem + i) for i in range(12)], spill=True)
+        kb = max(self.kof(s) for s in v.slots)
         self.release(v.slots)
-        return (elem, list(v.signs))
+        return (elem, list(v.signs), kb)
 
     def fill(self, handle):
-        elem, signs = handle
+        elem, signs, kb = handle
         s = self.alloc(12)
-        self.gload(K_STATE, [(s[i], elem + i) for i in range(12)])
+        self.gload(K_STATE, [(s[i], elem + i) for i in range(12)], kbound=kb)
         return V12(s, signs)
 
 
@@ -953,7 +986,8 @@ class Emu:
                     acc = [0] * NL
                     for s, c in terms:
                         acc = [x + c * y for x, y in zip(acc, self.slot[s])]
-                    res.append((dst, vred(weak_norm(acc))))
+                    acc = weak_norm(acc)
+                    res.append((dst, vred(acc) if st.get("vred", True) else acc))
                 for d, v in res:
                     self.slot[d] = v
             elif op == OP_GLOAD:
@@ -1061,7 +1095,7 @@ def encode(builder):
                         tbl.append(s | ((c & 0xFF) << 8))
             for ln in lanes_pad(st["lanes"], None):
                 tbl.append(0 if ln is None else (ln[0] | (1 << 7)))
-            hdr += [op | (nt << 8), 0, off, 0]
+            hdr += [op | (nt << 8), int(st.get("vred", True)), off, 0]
         elif op in (OP_GLOAD, OP_GSTORE):
             for ln in lanes_pad(st["lanes"], None):
                 if ln is None:
@@ -1111,7 +1145,7 @@ def prog_timing(T, epi, nloop=400, lin=False):
             lanes.append({"dst": o["dst"], "terms": enc, "alpha": o.get("alpha", 1), "beta": o.get("beta", 0), "e": o.get("e", ZERO)})
         b.steps.append({"op": OP_MULACC, "T": T, "lanes": lanes, "epi": bool(epi)})
     b.endloop()
-    b.gstore(K_STATE, [(v[i], i) for i in range(12)])
+    b.gstore(K_STATE, [(v[i], i) for i in range(12)], spill=True)   # timing only: values are meaningless
     return b
 
 

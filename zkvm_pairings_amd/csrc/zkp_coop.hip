@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 for (int i = 0; i < NL; i++) r[i] += c * x[i];
             }
             weak_norm(r);
-            vred(r);
+            if (h1 & 1) vred(r);   // only where the generator's static value bound asks for it
             const uint32_t ew = tbl[off + arg * LIG + lig];
             if (active && ((ew >> 7) & 1)) lds_st(lds, gbase + (int)(ew & 63), S, r);
         } else if (op == OP_GLOAD) {
