@@ -107,6 +107,55 @@ def test_validity_golden_and_oracle(eng, model_vectors, ref_kats):
     assert eng.g1_is_valid(pts[:0]).shape == (0,)
 
 
+def test_validity_of_small_order_and_cofactor_points(keng, model_vectors):
+    """on-curve points OUTSIDE the prime-order subgroup that drive the Jacobian arithmetic through its exceptional
+    cases (P + (-P), doubling inside an addition, infinity mid-way): the order-3 points (0, +-2) of E(Fp), and
+    cofactor-torsion points [r]R for on-curve R.  Status must agree with the affine reference semantics (oracle)."""
+    H_ = lambda s: int(s, 16)
+    g = model_vectors["groups"]
+    pts1 = [o.ints_to_arr([0, 2]), o.ints_to_arr([0, m.P - 2])]
+    for v in g["g1_validity"]:
+        if v["status"] == 2:
+            base = A(v["p"])
+            tors, inf = o.g1_mul(base, m.R_ORDER)              # kills the G1 component: order divides the cofactor
+            if not inf:
+                pts1.append(tors)
+                for k in (3, 11, 3 * 11):
+                    q, qinf = o.g1_mul(tors, 0x396c8c005555e1568c00aaab0000aaab // k)
+                    if not qinf:
+                        pts1.append(q)
+    pts1 = np.stack(pts1)
+    want1 = [o.g1_is_valid(p) for p in pts1]
+    assert all(o.g1_is_on_curve(p) for p in pts1) and set(want1) == {2}
+    assert keng.g1_is_valid(pts1).tolist() == want1
+    pts2 = []
+    for v in g["g2_validity"]:
+        if v["status"] == 2:
+            base = A(v["p"])
+            tors, inf = o.g2_mul(base, m.R_ORDER)
+            if not inf:
+                pts2.append(tors)
+                for k in (13, 23, 13 * 13):
+                    q, qinf = o.g2_mul(tors, k)
+                    if not qinf:
+                        pts2.append(q)
+    pts2 = np.stack(pts2)
+    want2 = [o.g2_is_valid(p) for p in pts2]
+    assert all(o.g2_is_on_curve(p) for p in pts2)
+    assert keng.g2_is_valid(pts2).tolist() == want2
+    # a large mixed batch: honest points with torsion points sprinkled in
+    from zkvm_pairings_amd import synthetic
+    n = 1000
+    h1, _ = keng.g1_mul(synthetic.G1_GENERATOR, synthetic.scalars(71, n))
+    h2, _ = keng.g2_mul(synthetic.G2_GENERATOR, synthetic.scalars(72, n))
+    exp1, exp2 = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    for j in range(0, n, 37):
+        h1[j] = pts1[j % len(pts1)]; exp1[j] = 2
+        h2[j] = pts2[j % len(pts2)]; exp2[j] = want2[j % len(pts2)]
+    h1[5, 6] ^= np.uint64(1); exp1[5] = 1      # off the curve
+    assert np.array_equal(keng.g1_is_valid(h1), exp1) and np.array_equal(keng.g2_is_valid(h2), exp2)
+
+
 def test_pairing_golden(keng, model_vectors):
     from zkvm_pairings_amd import synthetic
     pr = model_vectors["pairing"]

@@ -512,6 +512,160 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
     emit(l0, l1, l2);
 }
 
+// =============================================================================== validity checks on the 28-bit core
+// G1Affine::is_valid / G2Affine::is_valid (reference src/g1.rs:49-62, src/g2.rs:57-69) with Jacobian arithmetic and
+// no inversion.  Zero tests canonicalise (one reduction); every exceptional case of the group law is handled so
+// that the status agrees with the affine reference semantics on EVERY input (small-order points included).
+__device__ __forceinline__ bool f_is_zero(const Fp28& a) {
+    Acc acc;
+    acc_zero(acc);
+#pragma unroll
+    for (int i = 0; i < NL; i++) acc.c[i] = a.l[i];
+    int32_t x[NL];
+    acc_reduce(x, acc);
+    uint32_t f[NL];
+    canon28(f, x);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) o |= f[i];
+    return o == 0;
+}
+__device__ __forceinline__ Fp28 f_const(const int32_t* k) { Fp28 r; f_set(r, k); return r; }
+__device__ __forceinline__ Fp28 f_vred(Fp28 a) { vred(a.l); return a; }
+
+// ---- generic Jacobian arithmetic over an "element" E with by-value ops supplied by the policy F
+//      (F1: Fp, one lane per point; F2: Fp2 spread over a lane pair)
+struct F1 {
+    int c;
+    __device__ Fp28 sqr(const Fp28& a) const { return f_mul_v(a, a); }
+    __device__ Fp28 mul(const Fp28& a, const Fp28& b) const { return f_mul_v(a, b); }
+    __device__ bool is_zero(const Fp28& a) const { return f_is_zero(a); }
+    __device__ Fp28 one() const { return f_const(K28_ONE); }
+};
+struct F2 {
+    int c;   // which Fp2 coefficient this lane holds
+    __device__ Fp28 sqr(const Fp28& a) const { return c_sqr(a, c); }
+    __device__ Fp28 mul(const Fp28& a, const Fp28& b) const { return c_mul(a, b, c); }
+    __device__ bool is_zero(const Fp28& a) const {
+        const int z = f_is_zero(a) ? 1 : 0;
+        const int zo = __builtin_amdgcn_update_dpp(0, z, 0xB1, 0xf, 0xf, false);
+        return z && zo;
+    }
+    __device__ Fp28 one() const { Fp28 r; if (c == 0) f_set(r, K28_ONE); else f_zero(r); return r; }
+};
+struct JacP { Fp28 x, y, z; };   // z == 0 <=> infinity
+
+// a = 0 doubling (dbl-2009-l).  Infinity and y = 0 need no special case: Z3 = 2 Y Z vanishes.
+template <class F>
+__device__ __forceinline__ void jac_dbl(const F& f, JacP& p) {
+    Fp28 A = f.sqr(p.x), B = f.sqr(p.y), C = f.sqr(B);
+    Fp28 D = c_sub(c_sub(f.sqr(c_add(p.x, B)), A), C);
+    D = c_dbl(D);
+    Fp28 E = c_add(c_add(A, A), A);
+    Fp28 Fq = f.sqr(E);
+    Fp28 X3 = c_sub(c_sub(Fq, D), D);
+    Fp28 Z3 = c_dbl(f.mul(p.y, p.z));
+    Fp28 Y3 = c_sub(f.mul(E, c_sub(D, X3)), c_dbl(c_dbl(c_dbl(C))));
+    p.x = f_vred(X3); p.y = f_vred(Y3); p.z = f_vred(Z3);
+}
+// mixed addition p += (qx, qy) (madd-2007-bl) with every exceptional case
+template <class F>
+__device__ __forceinline__ void jac_madd(const F& f, JacP& p, const Fp28& qx, const Fp28& qy) {
+    if (f.is_zero(p.z)) { p.x = qx; p.y = qy; p.z = f.one(); return; }
+    Fp28 Z1Z1 = f.sqr(p.z);
+    Fp28 U2 = f.mul(qx, Z1Z1);
+    Fp28 S2 = f.mul(f.mul(qy, p.z), Z1Z1);
+    Fp28 H = c_sub(U2, p.x);
+    Fp28 rr = c_sub(S2, p.y);
+    if (f.is_zero(H)) {
+        if (f.is_zero(rr)) { p.x = qx; p.y = qy; p.z = f.one(); jac_dbl(f, p); return; }
+        f_zero(p.z);   // P + (-P)
+        return;
+    }
+    rr = c_dbl(rr);
+    Fp28 HH = f.sqr(H);
+    Fp28 I = c_dbl(c_dbl(HH));
+    Fp28 J = f.mul(H, I);
+    Fp28 V = f.mul(p.x, I);
+    Fp28 X3 = c_sub(c_sub(c_sub(f.sqr(rr), J), V), V);
+    Fp28 Y3 = c_sub(f.mul(rr, c_sub(V, X3)), c_dbl(f.mul(p.y, J)));
+    Fp28 Z3 = c_sub(c_sub(f.sqr(c_add(p.z, H)), Z1Z1), HH);
+    p.x = f_vred(X3); p.y = f_vred(Y3); p.z = f_vred(Z3);
+}
+// p = [k] (qx, qy), k given as nwords 64-bit words, MSB first
+template <class F>
+__device__ __forceinline__ void jac_mul(const F& f, JacP& p, const Fp28& qx, const Fp28& qy, const uint64_t* k, int nwords) {
+    p.x = f.one(); p.y = f.one(); f_zero(p.z);
+#pragma unroll 1
+    for (int w = nwords - 1; w >= 0; w--) {
+        const uint64_t e = k[w];
+#pragma unroll 1
+        for (int b = 63; b >= 0; b--) {
+            jac_dbl(f, p);
+            if ((e >> b) & 1) jac_madd(f, p, qx, qy);
+        }
+    }
+}
+// Jacobian p == affine (qx, qy) ?  (infinity never equals a finite point)
+template <class F>
+__device__ __forceinline__ bool jac_eq_affine(const F& f, const JacP& p, const Fp28& qx, const Fp28& qy) {
+    if (f.is_zero(p.z)) return false;
+    Fp28 z2 = f.sqr(p.z);
+    Fp28 z3 = f.mul(z2, p.z);
+    const bool ex = f.is_zero(c_sub(f.mul(qx, z2), p.x));
+    const bool ey = f.is_zero(c_sub(f.mul(qy, z3), p.y));
+    return ex && ey;
+}
+
+// one lane per point: 0 valid / 1 not on curve / 2 not torsion free  (-[X^2]P == (beta x, y), src/g1.rs:111-115)
+__global__ void __launch_bounds__(64, 2) k_g1_valid28(const uint64_t* g1, const uint8_t* inf, uint32_t n, uint8_t* status) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    if (inf && inf[i]) { status[i] = 0; return; }
+    F1 f{0};
+    Fp28 x, y;
+    fp28_from_wire(x, g1 + 12 * (size_t)i);
+    fp28_from_wire(y, g1 + 12 * (size_t)i + 6);
+    Fp28 lhs = f.sqr(y);
+    Fp28 rhs = c_add(f.mul(f.sqr(x), x), f_const(K28_B));
+    if (!f.is_zero(c_sub(lhs, rhs))) { status[i] = 1; return; }
+    const uint64_t x2[2] = {0x0000000100000000ULL, 0xac45a4010001a402ULL};   // X^2, X = 0xd201000000010000
+    JacP p;
+    jac_mul(f, p, x, y, x2, 2);
+    Fp28 bx = f.mul(x, f_const(K28_BETA));
+    status[i] = jac_eq_affine(f, p, bx, c_neg(y)) ? 0 : 2;
+}
+
+// two lanes per point: psi(P) == -[X]P  (src/g2.rs:166-170)
+__global__ void __launch_bounds__(64, 2) k_g2_valid28(const uint64_t* g2, const uint8_t* inf, uint32_t n, uint8_t* status) {
+    const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
+    const int c = (int)(tid & 1);
+    uint32_t i = tid >> 1;
+    const bool live = i < n;
+    if (!live) i = n - 1;
+    const bool is_inf = inf && inf[i];
+    F2 f{c};
+    Fp28 x, y;
+    fp28_from_wire(x, g2 + 24 * (size_t)i + 6 * c);
+    fp28_from_wire(y, g2 + 24 * (size_t)i + 12 + 6 * c);
+    uint8_t st;
+    Fp28 lhs = f.sqr(y);
+    Fp28 rhs = c_add(f.mul(f.sqr(x), x), f_const(K28_B));     // b' = 4 (1 + u): both coefficients are 4
+    if (!f.is_zero(c_sub(lhs, rhs))) {
+        st = 1;
+    } else {
+        const uint64_t xs[1] = {0xd201000000010000ULL};
+        JacP p;
+        jac_mul(f, p, x, y, xs, 1);
+        // psi(P) = (conj(x) PSI_X, conj(y) PSI_Y); compare [X]P with (psi_x, -psi_y)
+        Fp28 cx = c ? c_neg(x) : x, cy = c ? c_neg(y) : y;
+        Fp28 kx = f_const(c ? K28_PSI_X_1 : K28_PSI_X_0), ky = f_const(c ? K28_PSI_Y_1 : K28_PSI_Y_0);
+        Fp28 px = f.mul(cx, kx), py = f.mul(cy, ky);
+        st = jac_eq_affine(f, p, px, c_neg(py)) ? 0 : 2;
+    }
+    if (live && c == 0) status[i] = is_inf ? 0 : st;
+}
+
 // one lane per check: state[ST_NINV] = state[ST_N]^-1 (Fermat, a^(p-2); reference src/fp.rs:307-319)
 __global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks, uint32_t nc) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
@@ -773,6 +927,17 @@ hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, flo
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return hipSuccess;
+}
+
+hipError_t coop_g1_valid(const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_g1_valid28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, inf, (uint32_t)n, status);
+    return hipGetLastError();
+}
+hipError_t coop_g2_valid(const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_g2_valid28, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, g2, inf, (uint32_t)n, status);
+    return hipGetLastError();
 }
 
 hipError_t coop_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, hipStream_t s) {

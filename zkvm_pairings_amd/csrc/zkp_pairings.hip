@@ -505,6 +505,10 @@ int zkp_g1_is_valid_batch_dev(zkp_ctx* c, const void* g1, const void* inf, size_
     int rc = bind(c);
     if (rc) return rc;
     if (!n) return ZKP_OK;
+    if (zkp::coop_selected(&c->coop, c->kernel)) {
+        HIPCHK(c, zkp::coop_g1_valid((const uint64_t*)g1, (const uint8_t*)inf, n, (uint8_t*)status, S(stream)));
+        return ZKP_OK;
+    }
     hipLaunchKernelGGL(k_g1_valid, dim3(grid_for(n, TPB)), dim3(TPB), 0, S(stream), (const uint64_t*)g1, (const uint8_t*)inf, n, (uint8_t*)status);
     HIPCHK(c, hipGetLastError());
     return ZKP_OK;
@@ -514,6 +518,10 @@ int zkp_g2_is_valid_batch_dev(zkp_ctx* c, const void* g2, const void* inf, size_
     int rc = bind(c);
     if (rc) return rc;
     if (!n) return ZKP_OK;
+    if (zkp::coop_selected(&c->coop, c->kernel)) {
+        HIPCHK(c, zkp::coop_g2_valid((const uint64_t*)g2, (const uint8_t*)inf, n, (uint8_t*)status, S(stream)));
+        return ZKP_OK;
+    }
     hipLaunchKernelGGL(k_g2_valid, dim3(grid_for(n, TPB)), dim3(TPB), 0, S(stream), (const uint64_t*)g2, (const uint8_t*)inf, n, (uint8_t*)status);
     HIPCHK(c, hipGetLastError());
     return ZKP_OK;
