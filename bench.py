@@ -127,7 +127,8 @@ def main():
             "roofline": {"bound": "valu-int (neither hbm nor mfma: 384-bit modular arithmetic, >7000 MAC/B)",
                          "achieved": achieved / 1e12, "peak": PEAK_MACS / 1e12, "unit": "T u32-MAC/s",
                          "frac": achieved / PEAK_MACS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "algorithmic_macs_per_pairing": MACS_PER_PAIRING},
+                         "kernel_ms": kern_ms, "algorithmic_macs_per_pairing": MACS_PER_PAIRING,
+                         "launch": "one pass over the resident batch = k_prep_lines + k_coop(miller) + k_coop(fexp_a) + k_batch_inv + k_coop(fexp_c) per 2^16-check chunk, chunks on two overlapped HIP streams; kernel_ms is that pass timed with HIP events on the launching stream (profiles/r01/v7_pass_timeline.txt)"},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
