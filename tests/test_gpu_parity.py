@@ -62,7 +62,8 @@ def test_fp_op_precompile_shape(eng):
     assert np.array_equal(eng.fp_op(2, a, b), mul)
 
 
-def test_scalar_mul_golden_and_oracle(eng, model_vectors):
+def test_scalar_mul_golden_and_oracle(keng, model_vectors):
+    eng = keng
     from zkvm_pairings_amd import synthetic
     g = model_vectors["groups"]
     ks = [H(v["k"]) for v in g["g1_mul"]]
@@ -87,7 +88,8 @@ def test_scalar_mul_golden_and_oracle(eng, model_vectors):
     assert np.array_equal(r2, o.g2_mul_batch(b2, s, NTHREADS))
 
 
-def test_validity_golden_and_oracle(eng, model_vectors, ref_kats):
+def test_validity_golden_and_oracle(keng, model_vectors, ref_kats):
+    eng = keng
     from zkvm_pairings_amd import synthetic
     g = model_vectors["groups"]
     pts = np.stack([A(v["p"]) for v in g["g1_validity"]] + [synthetic.G1_GENERATOR, A(ref_kats["g1_double"]["b"])])

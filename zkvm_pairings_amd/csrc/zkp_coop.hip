@@ -666,23 +666,84 @@ __global__ void __launch_bounds__(64, 2) k_g2_valid28(const uint64_t* g2, const 
     if (live && c == 0) status[i] = is_inf ? 0 : st;
 }
 
-// one lane per check: state[ST_NINV] = state[ST_N]^-1 (Fermat, a^(p-2); reference src/fp.rs:307-319)
-__global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks, uint32_t nc) {
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_checks) return;
-    Fp28 a, res;
-    rec_load(a, state + ((size_t)ZKP_COOP_ST_N * nc + i) * 4);
-    f_set(res, K28_ONE);
-    // p - 2 in 28-bit limbs: p's limbs with 2 subtracted from limb 0 (no borrow: limb 0 = 0xfffaaab)
+// a^(p-2) (Fermat; reference src/fp.rs:307-319); a == 0 gives 0
+__device__ __forceinline__ Fp28 f_inv(const Fp28& a) {
+    Fp28 res = f_const(K28_ONE);
 #pragma unroll 1
     for (int w = NL - 1; w >= 0; w--) {
         const uint32_t e = (uint32_t)K28_P[w] - (w == 0 ? 2u : 0u);
 #pragma unroll 1
         for (int b = W - 1; b >= 0; b--) {
             fp28_mul(res, res, res);
-            if ((e >> b) & 1) fp28_mul(res, res, a);   // wave-uniform branch: the exponent is a constant
+            if ((e >> b) & 1) fp28_mul(res, res, a);
         }
     }
+    return res;
+}
+
+// [k] P for 256-bit scalars, affine in / affine out (&G1Affine * &Fr, reference src/g1.rs:130-153 without its dropped
+// bit 0; src/g2.rs:185-208).  One lane per G1 point; two lanes per G2 point.
+__global__ void __launch_bounds__(64, 2) k_g1_mul28(const uint64_t* base, size_t stride, const uint64_t* sc, uint32_t n, uint64_t* out, uint8_t* out_inf) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    F1 f{0};
+    Fp28 x, y;
+    fp28_from_wire(x, base + stride * i);
+    fp28_from_wire(y, base + stride * i + 6);
+    const uint64_t k[4] = {sc[4 * (size_t)i], sc[4 * (size_t)i + 1], sc[4 * (size_t)i + 2], sc[4 * (size_t)i + 3]};
+    JacP p;
+    jac_mul(f, p, x, y, k, 4);
+    const bool inf = f.is_zero(p.z);
+    Fp28 zi = f_inv(p.z);
+    Fp28 zi2 = f.sqr(zi);
+    Fp28 ax = f.mul(p.x, zi2), ay = f.mul(p.y, f.mul(zi2, zi));
+    if (inf) { f_zero(ax); ay = f_const(K28_ONE); }      // identity is (0, 1, infinity), reference src/g1.rs:25-31
+    fp28_to_wire(out + 12 * (size_t)i, ax);
+    fp28_to_wire(out + 12 * (size_t)i + 6, ay);
+    if (out_inf) out_inf[i] = inf ? 1 : 0;
+}
+__global__ void __launch_bounds__(64, 2) k_g2_mul28(const uint64_t* base, size_t stride, const uint64_t* sc, uint32_t n, uint64_t* out, uint8_t* out_inf) {
+    const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
+    const int c = (int)(tid & 1);
+    uint32_t i = tid >> 1;
+    const bool live = i < n;
+    if (!live) i = n - 1;
+    F2 f{c};
+    Fp28 x, y;
+    fp28_from_wire(x, base + stride * i + 6 * c);
+    fp28_from_wire(y, base + stride * i + 12 + 6 * c);
+    const uint64_t k[4] = {sc[4 * (size_t)i], sc[4 * (size_t)i + 1], sc[4 * (size_t)i + 2], sc[4 * (size_t)i + 3]};
+    JacP p;
+    jac_mul(f, p, x, y, k, 4);
+    const bool inf = f.is_zero(p.z);
+    // 1 / (z0 + z1 u) = (z0 - z1 u) / (z0^2 + z1^2)   (reference src/fp2.rs:278-296); both lanes invert the norm
+    Fp28 o;
+    swap_pair(o, p.z);
+    Acc acc;
+    acc_zero(acc);
+    acc_mul(acc, p.z.l, p.z.l);
+    acc_mul(acc, o.l, o.l);
+    Fp28 nrm;
+    acc_reduce(nrm.l, acc);
+    Fp28 ninv = f_inv(nrm);
+    Fp28 zi = f_mul_v(c ? c_neg(p.z) : p.z, ninv);
+    Fp28 zi2 = f.sqr(zi);
+    Fp28 ax = f.mul(p.x, zi2), ay = f.mul(p.y, f.mul(zi2, zi));
+    if (inf) { f_zero(ax); ay = f.one(); }
+    if (live) {
+        fp28_to_wire(out + 24 * (size_t)i + 6 * c, ax);
+        fp28_to_wire(out + 24 * (size_t)i + 12 + 6 * c, ay);
+        if (out_inf && c == 0) out_inf[i] = inf ? 1 : 0;
+    }
+}
+
+// one lane per check: state[ST_NINV] = state[ST_N]^-1 (Fermat, a^(p-2); reference src/fp.rs:307-319)
+__global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks, uint32_t nc) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_checks) return;
+    Fp28 a;
+    rec_load(a, state + ((size_t)ZKP_COOP_ST_N * nc + i) * 4);
+    Fp28 res = f_inv(a);
     rec_store(state + ((size_t)ZKP_COOP_ST_NINV * nc + i) * 4, res);
 }
 
@@ -937,6 +998,17 @@ hipError_t coop_g1_valid(const uint64_t* g1, const uint8_t* inf, size_t n, uint8
 hipError_t coop_g2_valid(const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(k_g2_valid28, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, g2, inf, (uint32_t)n, status);
+    return hipGetLastError();
+}
+
+hipError_t coop_g1_mul(const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_g1_mul28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, base, stride, sc, (uint32_t)n, out, out_inf);
+    return hipGetLastError();
+}
+hipError_t coop_g2_mul(const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_g2_mul28, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, base, stride, sc, (uint32_t)n, out, out_inf);
     return hipGetLastError();
 }
 

@@ -26,6 +26,8 @@ hipError_t coop_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_
 // G1/G2 is_valid on the 28-bit core (status 0 / 1 / 2)
 hipError_t coop_g1_valid(const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s);
 hipError_t coop_g2_valid(const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s);
+hipError_t coop_g1_mul(const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf, hipStream_t s);
+hipError_t coop_g2_mul(const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf, hipStream_t s);
 hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, float* ms);
 hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks,
                        size_t k, uint64_t* out, hipStream_t s);

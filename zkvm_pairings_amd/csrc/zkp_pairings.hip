@@ -531,6 +531,10 @@ int zkp_g1_mul_batch_dev(zkp_ctx* c, const void* base, size_t stride, const void
     int rc = bind(c);
     if (rc) return rc;
     if (!n) return ZKP_OK;
+    if (zkp::coop_selected(&c->coop, c->kernel)) {
+        HIPCHK(c, zkp::coop_g1_mul((const uint64_t*)base, stride, (const uint64_t*)sc, n, (uint64_t*)out, (uint8_t*)out_inf, S(stream)));
+        return ZKP_OK;
+    }
     hipLaunchKernelGGL(k_g1_mul, dim3(grid_for(n, TPB)), dim3(TPB), 0, S(stream), (const uint64_t*)base, stride, (const uint64_t*)sc, n, (uint64_t*)out, (uint8_t*)out_inf);
     HIPCHK(c, hipGetLastError());
     return ZKP_OK;
@@ -540,6 +544,10 @@ int zkp_g2_mul_batch_dev(zkp_ctx* c, const void* base, size_t stride, const void
     int rc = bind(c);
     if (rc) return rc;
     if (!n) return ZKP_OK;
+    if (zkp::coop_selected(&c->coop, c->kernel)) {
+        HIPCHK(c, zkp::coop_g2_mul((const uint64_t*)base, stride, (const uint64_t*)sc, n, (uint64_t*)out, (uint8_t*)out_inf, S(stream)));
+        return ZKP_OK;
+    }
     hipLaunchKernelGGL(k_g2_mul, dim3(grid_for(n, TPB)), dim3(TPB), 0, S(stream), (const uint64_t*)base, stride, (const uint64_t*)sc, n, (uint64_t*)out, (uint8_t*)out_inf);
     HIPCHK(c, hipGetLastError());
     return ZKP_OK;
