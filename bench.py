@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- BLS12-381 pairings/s on synthetic random (G1,G2) pairs (BASELINE.json metric).
 
-One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).  A step = one pass of the hot path
-over this rank's resident batch: fused Miller loop + final exponentiation -> Gt (bit-exact vs the
-CPU oracle on a sample) + the Gt==identity flags, then ONE all-reduce(MIN) of the per-rank AND flag
-over RCCL (the only collective the path has).  Inputs are generated on the GPU before the timed
-region and stay resident in HBM.  Weak scaling: 2^17 pairs per GPU => 2^20 pairs at 8 GPUs."""
+One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).  The workload is BASELINE.json's: ONE batch of
+2^20 random (G1,G2) pairs, sharded in contiguous blocks over the ranks (strong scaling: 2^20 pairs on 1 GPU,
+2^17 per GPU on 8).  A step = one pass of the hot path over this rank's resident shard: fused Miller loop + final
+exponentiation -> Gt (bit-exact vs the CPU oracle on a sample) + the Gt==identity flags, then ONE
+all-reduce(MIN) of the per-rank AND flag over RCCL (the only collective the path has).  Inputs are generated on
+the GPU before the timed region and stay resident in HBM."""
 import argparse
 import json
 import os
@@ -15,7 +16,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PAIRS_PER_GPU = 1 << 17
+GLOBAL_PAIRS = 1 << 20
+PMC_PASS_PAIRS = 1 << 17   # size of the pass profiles/r01/pmc/traffic.json was measured on
 # algorithmic work per pairing with the reference-shaped tower =
 # 21,869 Fp-mul-equivalents x 300 32x32->64 multiply-adds (CIOS, 12 limbs)
 MACS_PER_PAIRING = 21869 * 300
@@ -29,7 +31,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs-per-gpu", type=int, default=PAIRS_PER_GPU)
+    ap.add_argument("--pairs", type=int, default=GLOBAL_PAIRS, help="global batch, sharded over the ranks")
+    ap.add_argument("--pairs-per-gpu", type=int, default=0, help="override: fixed shard per rank (weak scaling)")
     ap.add_argument("--kernel", default=os.environ.get("ZKP_KERNEL", "auto"))
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -54,9 +57,15 @@ def main():
     eng = z.PairingEngine(local_rank)
     if args.kernel != "auto":
         eng.set_kernel(args.kernel)
-    n = args.pairs_per_gpu
-    # rank-disjoint slices of one global seeded stream (contiguous blocks per GPU)
-    g1, g2, _, _ = synthetic.random_pairs(eng, n, seed=synthetic.SEED, offset=rank * n, device_tensors=True)
+    # rank-disjoint contiguous slices of one global seeded stream
+    if args.pairs_per_gpu:
+        lo, hi = rank * args.pairs_per_gpu, (rank + 1) * args.pairs_per_gpu
+        global_pairs, scaling = world * args.pairs_per_gpu, "weak"
+    else:
+        lo, hi = zdist.shard_range(args.pairs, rank, world)
+        global_pairs, scaling = args.pairs, "strong"
+    n = hi - lo
+    g1, g2, _, _ = synthetic.random_pairs(eng, n, seed=synthetic.SEED, offset=lo, device_tensors=True)
     out_gt = torch.empty((n, 72), dtype=torch.int64, device=dev)
     ok = torch.empty(n, dtype=torch.uint8, device=dev)
     flag = torch.empty(1, dtype=torch.int32, device=dev)
@@ -91,13 +100,13 @@ def main():
 
     line = None
     if rank == 0:
-        value = world * n * args.steps / dt
+        value = global_pairs * args.steps / dt
         achieved = (n * MACS_PER_PAIRING) / (kern_ms * 1e-3)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01", "pmc", "traffic.json")
-        if os.path.exists(tpath) and n == PAIRS_PER_GPU and args.kernel in ("auto", "coop"):
-            with open(tpath) as tf:   # rocprofv3 PMC passes of this same command, gfx950-corrected (see file)
-                traffic = json.load(tf)["hbm_bytes_per_step"]
+        if os.path.exists(tpath) and args.kernel in ("auto", "coop"):
+            with open(tpath) as tf:   # rocprofv3 PMC passes over a 2^17-pair pass, gfx950-corrected (see file); linear in n
+                traffic = json.load(tf)["hbm_bytes_per_step"] * n / PMC_PASS_PAIRS
         # bit-exact parity of a seeded sample vs the CPU oracle + timing of the oracle on the host cores
         cpu = None
         parity = None
@@ -115,14 +124,14 @@ def main():
             got = out_gt[idx].cpu().numpy().view(np.uint64)
             parity = bool(np.array_equal(got, want))
             cpu = {"value": ns / tcpu, "unit": "pairings/s", "cores": cores, "kind": "port",
-                   "sample": "%d of this rank's %d pairs (every %d-th), CPU restatement oracle/, %d threads" % (ns, n, n // ns, cores)}
+                   "sample": "%d of rank 0's %d pairs (every %d-th), CPU restatement oracle/, %d threads" % (ns, n, n // ns, cores)}
         line = {
-            "metric": "BLS12-381 pairings/s on random (G1,G2) pairs; bit-exact Gt vs CPU oracle",
+            "metric": "BLS12-381 pairings/s on 2^20 random (G1,G2) pairs; bit-exact Gt vs ref (CPU oracle: the reference's pairings.rs is empty)",
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "2^%d random (G1,G2) pairs per GPU (2^20 at 8 GPUs): fused Miller loop + final exponentiation, Gt + identity flags out, 1 RCCL all-reduce(MIN) of the AND flag" % (n.bit_length() - 1),
-                       "pairs_per_gpu": n, "global_pairs": world * n, "kernel_family": args.kernel, "all_ok_flag": all_ok,
+            "config": {"workload": "batch of %d random (G1,G2) pairs (BASELINE config 3) sharded over %d GPU(s): fused Miller loop + final exponentiation, Gt + identity flags out, 1 RCCL all-reduce(MIN) of the AND flag" % (global_pairs, world),
+                       "pairs_per_gpu": n, "global_pairs": global_pairs, "kernel_family": args.kernel, "all_ok_flag": all_ok,
                        "gt_sample_bit_exact": parity},
             "roofline": {"bound": "valu-int (neither hbm nor mfma: 384-bit modular arithmetic, >7000 MAC/B)",
                          "achieved": achieved / 1e12, "peak": PEAK_MACS / 1e12, "unit": "T u32-MAC/s",
