@@ -48,11 +48,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test-only knobs to rehearse N > 1 on a one-GPU box: every rank on cuda:0, gloo instead of RCCL
+    if os.environ.get("ZKP_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("ZKP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     eng = z.PairingEngine(local_rank)
     if args.kernel != "auto":

@@ -430,6 +430,20 @@ def test_validation_mode_rejects_noncanonical(eng):
         eng.set_validate(False)
 
 
+def test_pure_c_consumer_of_the_abi(tmp_path):
+    """integration/c/zkp_smoke.c: the boundary used from plain C (no Python, no torch types)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "zkp_smoke")
+    libdir = os.path.join(root, "zkvm_pairings_amd")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "integration", "c", "zkp_smoke.c"),
+                           "-L", libdir, "-lzkp_pairings", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "0x1250ebd871fc0a92" in out.stdout and "C ABI smoke ok" in out.stdout
+
+
 def test_reference_api_mirror():
     """pairing()/multi_miller_loop()/final_exponentiation()/Gt::identity() object API."""
     import zkvm_pairings_amd as z
