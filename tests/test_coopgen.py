@@ -59,6 +59,23 @@ def test_infinity_pair_gives_neutral_lines():
     assert em.wire_out == m.f12_flat_ints(m.multi_miller_loop([(m.G1_GEN, m.G2_GEN)]))
 
 
+def test_grouped_miller_join_matches_single_loop(model_vectors):
+    """k > 4 pairs per check: groups of <= 4 pairs run separate Miller loops, f12mul joins them.
+    Emulated on the 3-pair vector split 2 + 1."""
+    H = lambda s: int(s, 16)
+    c = model_vectors["pairing"]["multi3"]
+    pairs = [((H(a[0]), H(a[1])), ((H(b[0]), H(b[1])), (H(b[2]), H(b[3])))) for a, b in zip(c["g1"], c["g2"])]
+    e0 = cg.Emu(lines=cg.model_lines(pairs[:2])).run(cg.prog_miller(2, False).steps)
+    e1 = cg.Emu(lines=cg.model_lines(pairs[2:])).run(cg.prog_miller(1, False).steps)
+    state = dict(e0.state)
+    for i in range(12):
+        state[cg.ST_G + i] = e1.state[cg.ST_F + i]      # the kernel's st_off argument
+    ew = cg.Emu(state=dict(state)).run(cg.prog_f12mul(True).steps)
+    assert ew.wire_out == [H(x) for x in c["miller"]]
+    es = cg.Emu(state=dict(state)).run(cg.prog_f12mul(False).steps)
+    assert [cg.from_mont(es.state[cg.ST_F + i]) for i in range(12)] == [H(x) for x in c["miller"]]
+
+
 def test_program_encoding_is_consistent():
     for name, mk in cg.PROGRAMS.items():
         b = mk()

@@ -205,7 +205,7 @@ def test_pairing_batch_vs_oracle(keng):
     assert keng.pairing(g1[:0], g2[:0]).shape == (0, 72)
 
 
-@pytest.mark.parametrize("k", [2, 3, 4, 5, 9])
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 9, 17])
 def test_multi_miller_vs_oracle(keng, k):
     from zkvm_pairings_amd import synthetic
     n_checks = 20
@@ -266,6 +266,42 @@ def test_properties_at_size(keng):
     assert not ok1.any() and not all1
     sel = np.arange(0, n, n // 64)
     assert np.array_equal(keng.pairing(g1[sel], g2[sel]), o.pairing_batch(g1[sel], g2[sel], nthreads=NTHREADS))
+
+
+@pytest.mark.parametrize("k", [6, 10])
+def test_pairing_check_many_pairs_per_check(keng, k, monkeypatch):
+    """k > 4 pairs per check (processed in groups of four on the cooperative path): cancelling products
+    prod_j e(P_j,Q_j) e(-P_j,Q_j) == 1, every third check broken, infinities in later groups; a chunked
+    multi-stream engine must agree with the oracle too."""
+    from zkvm_pairings_amd import PairingEngine, synthetic
+    n = 203
+    g1, g2, _, _ = synthetic.random_pairs(keng, n * k // 2, seed=555 + k)
+    neg = g1.copy()
+    for j in range(len(g1)):
+        neg[j, 6:] = o.to_limbs((m.P - o.from_limbs(g1[j, 6:])) % m.P)
+    G1 = np.stack([g1, neg], axis=1).reshape(n, k, 12).copy()
+    G2 = np.stack([g2, g2], axis=1).reshape(n, k, 24).copy()
+    inf1 = np.zeros((n, k), dtype=np.uint8)
+    inf1[1::3, k - 1] = 1          # drops e(-P,Q) of the last pair: the product is no longer one
+    inf1[2::3, k - 2:] = 1         # drops a whole cancelling pair: still one
+    G1, G2, inf1 = G1.reshape(n * k, 12), G2.reshape(n * k, 24), inf1.reshape(n * k)
+    expect = np.ones(n, dtype=np.uint8)
+    expect[1::3] = 0
+    ok, allok = keng.pairing_check(G1, G2, k, inf1, None)
+    assert np.array_equal(ok, expect) and not allok
+    sel = 12
+    ml = keng.multi_miller_loop(G1[:sel * k], G2[:sel * k], k, inf1[:sel * k], None)
+    assert np.array_equal(ml, o.multi_miller_loop_batch(G1[:sel * k], G2[:sel * k], sel, k, inf1[:sel * k], None))
+    assert np.array_equal(ok[:sel], o.pairing_check_batch(G1[:sel * k], G2[:sel * k], sel, k, inf1[:sel * k], None))
+    monkeypatch.setenv("ZKP_COOP_CHUNK", "64")
+    monkeypatch.setenv("ZKP_COOP_STREAMS", "3")
+    e = PairingEngine(0)
+    try:
+        ok2, allok2 = e.pairing_check(G1, G2, k, inf1, None)
+        assert np.array_equal(ok2, expect) and not allok2
+        assert np.array_equal(e.multi_miller_loop(G1[:sel * k], G2[:sel * k], k, inf1[:sel * k], None), ml)
+    finally:
+        e.close()
 
 
 def test_config2_full_batch_bit_exact(eng):

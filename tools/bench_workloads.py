@@ -41,6 +41,15 @@ for kern in ("coop", "thread"):
     eng.set_kernel(kern)
     dt = timed(lambda: eng.pairing_gt_check(g1, g2, 3, None, ok, flag))
     out["check3_%s_checks_per_s" % kern] = n / dt
+# k = 8 pairs per check: two groups of four on the cooperative path, joined by one Fp12 multiplication
+n8 = n // 4
+g1k, g2k, _, _ = synthetic.random_pairs(eng, 8 * n8, seed=8, device_tensors=True)
+ok8 = torch.empty(n8, dtype=torch.uint8, device=dev)
+for kern in ("coop", "thread"):
+    eng.set_kernel(kern)
+    dt = timed(lambda: eng.pairing_gt_check(g1k, g2k, 8, None, ok8, flag))
+    out["check8_%s_checks_per_s" % kern] = n8 / dt
+del g1k, g2k
 eng.set_kernel("auto")
 p1, p2 = g1[:n].contiguous(), g2[:n].contiguous()
 dt = timed(lambda: eng.g1_is_valid(p1))

@@ -624,6 +624,22 @@ def prog_miller(k, to_wire):
     return b
 
 
+def prog_f12mul(to_wire):
+    """ST_F <- ST_F * ST_G (or the canonical wire record of the product): joins the Miller values of the groups of
+    at most four pairs a check with k > 4 pairs is split into (prod conj(f_i) = conj(prod f_i))."""
+    b = Builder()
+    f = load_input(b, False, ST_F)
+    g = load_input(b, False, ST_G)
+    h = b.fp12_mul(f, f, g)
+    if to_wire:
+        raw1 = Lin.of(CONST_SLOT["RAW_ONE"])
+        b.mulacc([{"dst": g.slots[i], "bil": Bil([(h.lin(i), raw1, 1)])} for i in range(12)])
+        b.gstore(K_WIRE, [(g.slots[i], i) for i in range(12)])
+    else:
+        b.gstore(K_STATE, [(h.slots[i], ST_F + i) for i in range(12)])
+    return b
+
+
 def finish_output(b, v, to_wire, state_base, check_identity=False):
     t = b.alloc(12)
     if to_wire:
@@ -656,6 +672,7 @@ ST_N = 20       # 1 : n = N0^2 + N1^2 in Fp  (input of the batched inversion ker
 ST_NINV = 21    # 1 : n^-1                      (its output)
 ST_TI = 22      # 6 : t^-1 (Fp6), parked while conj(f)^2 is formed
 ST_SPILL = 28   # 8 x 12 spill areas used by the hard part
+ST_G = ST_SPILL  # 12: Miller value of a later group of pairs (k > 4), multiplied into ST_F before the final exponentiation
 ST_SIZE = ST_SPILL + 8 * 12
 
 
@@ -1158,6 +1175,8 @@ PROGRAMS = {
     "miller3_wire": lambda: prog_miller(3, True),
     "miller4_state": lambda: prog_miller(4, False),
     "miller4_wire": lambda: prog_miller(4, True),
+    "f12mul_state": lambda: prog_f12mul(False),
+    "f12mul_wire": lambda: prog_f12mul(True),
     "fexp_a_state": lambda: prog_fexp_a(False),
     "fexp_a_wire": lambda: prog_fexp_a(True),
     "fexp_c": lambda: prog_fexp_c(True),
@@ -1175,7 +1194,7 @@ def write_inc(path):
              "#pragma once", "#include <stdint.h>",
              "#define ZKP_COOP_G %d" % G, "#define ZKP_COOP_NSLOT_MAX %d" % NSLOT, "#define ZKP_COOP_NSLOT %d" % LDS_SLOTS,
              "#define ZKP_COOP_NCONST %d" % N_CONST, "#define ZKP_COOP_ST_SIZE %d" % ST_SIZE,
-             "#define ZKP_COOP_ST_N %d" % ST_N, "#define ZKP_COOP_ST_NINV %d" % ST_NINV,
+             "#define ZKP_COOP_ST_G %d" % ST_G, "#define ZKP_COOP_ST_N %d" % ST_N, "#define ZKP_COOP_ST_NINV %d" % ST_NINV,
              "#define ZKP_COOP_NLINES %d" % n_line_steps(),
              "#define ZKP_COOP_VRED_C %d" % VRED_C, "#define ZKP_COOP_VRED_SHIFT_IN %d" % VRED_SHIFT_IN,
              "#define ZKP_COOP_VRED_SHIFT_OUT %d" % VRED_SHIFT_OUT,

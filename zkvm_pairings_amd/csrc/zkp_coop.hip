@@ -54,6 +54,7 @@ struct CoopArgs {
     uint32_t k;
     uint32_t S;               // LDS plane stride (int4) of a group region (= the program's slot count)
     uint32_t nconst;          // constants the program references (prefix of the table)
+    uint32_t st_off;          // added to every K_STATE element index (where a group's Miller value lands)
 };
 
 // ---- LDS access: quad-plane SoA, record = 4 x int4 at off, off+S, off+2S, off+3S
@@ -240,7 +241,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 } else {
                     size_t rec;
                     if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + idx) * A.nc + check;
-                    else rec = (size_t)idx * A.nc + check;
+                    else rec = (size_t)(idx + A.st_off) * A.nc + check;
                     const int4* src = (arg == K_LINE ? A.lines : (const int4*)A.state) + rec * 4;
                     int4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
                     x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             lds_ld(x, lds, gbase + (int)(w & 63), S);
             if (arg == K_STATE) {
                 if (part) {
-                    int4* dst = A.state + ((size_t)idx * A.nc + check) * 4;
+                    int4* dst = A.state + ((size_t)(idx + A.st_off) * A.nc + check) * 4;
                     dst[0] = make_int4(x[0], x[1], x[2], x[3]);
                     dst[1] = make_int4(x[4], x[5], x[6], x[7]);
                     dst[2] = make_int4(x[8], x[9], x[10], x[11]);
@@ -454,25 +455,27 @@ __device__ __forceinline__ void add_step(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, c
 }
 
 // two lanes per pair: write the 68-step line stream of pair `pid` (check = pid / k, j = pid % k);
-// lane c writes the records of Fp2 coefficient c
+// lane c writes the records of Fp2 coefficient c.  The k pairs are pairs j0 .. j0+k-1 of the check's k_in
+// input pairs (k_in > k when a check is processed in groups of at most four pairs).
 #ifndef ZKP_PREP_WAVES
 #define ZKP_PREP_WAVES 2   // measured: 256 VGPRs (2 waves/SIMD) 6.6 ms, 168 -> 9.3 ms, 128 -> 11.4 ms per 2^17 pairs (spill traffic)
 #endif
 __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
-                                                       uint32_t n_pairs, uint32_t k, uint32_t nc, int4* lines) {
+                                                       uint32_t n_pairs, uint32_t k, uint32_t k_in, uint32_t j0, uint32_t nc, int4* lines) {
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
     const int c = (int)(tid & 1);
     uint32_t pid = tid >> 1;
     const bool live_lane = pid < n_pairs;
     if (!live_lane) pid = n_pairs - 1;   // keep both lanes of a pair (and the DPP swaps) well defined
     const uint32_t check = pid / k, j = pid - check * k;
-    const bool dead = (inf1 && inf1[pid]) || (inf2 && inf2[pid]);
+    const size_t src = (size_t)check * k_in + j0 + j;
+    const bool dead = (inf1 && inf1[src]) || (inf2 && inf2[src]);
     auto rec = [&](uint32_t step, uint32_t e) -> int4* { return lines + ((((size_t)step * k + j) * 6 + e) * nc + check) * 4; };
     Fp28 px, py, qx, qy;
-    fp28_from_wire(px, g1 + 12 * (size_t)pid);
-    fp28_from_wire(py, g1 + 12 * (size_t)pid + 6);
-    fp28_from_wire(qx, g2 + 24 * (size_t)pid + 6 * c);
-    fp28_from_wire(qy, g2 + 24 * (size_t)pid + 12 + 6 * c);
+    fp28_from_wire(px, g1 + 12 * src);
+    fp28_from_wire(py, g1 + 12 * src + 6);
+    fp28_from_wire(qx, g2 + 24 * src + 6 * c);
+    fp28_from_wire(qy, g2 + 24 * src + 12 + 6 * c);
     G2C r;
     r.x = qx;
     r.y = qy;
@@ -847,7 +850,7 @@ static hipError_t ensure_buf(int4** p, size_t* cap, size_t bytes) {
 }
 
 static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks, uint32_t nc, uint32_t k, const uint64_t* wire_in,
-                           uint64_t* wire_out, uint8_t* ok, int* all_ok) {
+                           uint64_t* wire_out, uint8_t* ok, int* all_ok, uint32_t st_off = 0) {
     hipStream_t s = pp->stream;
     CoopArgs a;
     a.hdr = d->progs[prog].hdr;
@@ -865,6 +868,7 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     if (d->progs[prog].nslot > (uint32_t)ZKP_COOP_NSLOT) return hipErrorInvalidValue;
     a.S = ZKP_COOP_NSLOT;
     a.nconst = d->progs[prog].nconst;
+    a.st_off = st_off;
     size_t lds_bytes = (size_t)(4 * ZKP_COOP_NCONST + GROUPS * (4 * ZKP_COOP_NSLOT + 3)) * 16;
     static const char* pad_env = getenv("ZKP_COOP_LDS_PAD");   // occupancy experiments only
     if (pad_env) lds_bytes += (size_t)atol(pad_env);
@@ -883,16 +887,44 @@ static int miller_prog(size_t k, bool wire) {
     }
 }
 
-bool coop_supports_k(size_t k) { return k >= 1 && k <= 4; }
+constexpr size_t MAX_GROUP = 4;   // pairs per Miller program; a check with more pairs is processed in groups
+bool coop_supports_k(size_t k) { return k >= 1 && k <= 0xffffu; }
 
+// line stream of pairs j0 .. j0+g-1 of each of the n checks starting at base_check (k_in pairs per check)
 static hipError_t prep(CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t base_check, uint32_t n,
-                       uint32_t k) {
+                       uint32_t k_in, uint32_t j0, uint32_t g) {
     hipStream_t s = pp->stream;
-    size_t p0 = base_check * k;
-    uint32_t n_pairs = n * k;
+    size_t p0 = base_check * k_in;
+    uint32_t n_pairs = n * g;
     hipLaunchKernelGGL(k_prep_lines, dim3((2 * n_pairs + 63) / 64), dim3(64), 0, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
-                       i2 ? i2 + p0 : nullptr, n_pairs, k, n, pp->lines);
+                       i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines);
     return hipGetLastError();
+}
+
+// multi_miller_loop of n checks of k pairs each on one pipeline.  k <= 4: one program.  k > 4: groups of at most
+// four pairs run their own Miller loop (the line buffer is reused), the group values are joined by f12mul
+// (prod_i f_i is the multi-Miller value; only the shared squarings are lost).  Result: state ST_F, or the
+// canonical wire record in `wire_out` when that is not null.
+static hipError_t miller_on_pipe(CoopDev* d, CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2,
+                                 size_t base, uint32_t n, size_t k, uint64_t* wire_out) {
+    hipError_t e;
+    if (k <= MAX_GROUP) {
+        if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, 0, (uint32_t)k)) != hipSuccess) return e;
+        return run_prog(d, pp, miller_prog(k, wire_out != nullptr), n, n, (uint32_t)k, nullptr, wire_out, nullptr, nullptr);
+    }
+    for (size_t j0 = 0; j0 < k; j0 += MAX_GROUP) {
+        const size_t g = k - j0 < MAX_GROUP ? k - j0 : MAX_GROUP;
+        if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, (uint32_t)j0, (uint32_t)g)) != hipSuccess) return e;
+        if ((e = run_prog(d, pp, miller_prog(g, false), n, n, (uint32_t)g, nullptr, nullptr, nullptr, nullptr, j0 ? ZKP_COOP_ST_G : 0)) != hipSuccess)
+            return e;
+        if (j0) {
+            const bool last = j0 + g == k;
+            if ((e = run_prog(d, pp, (last && wire_out) ? ZKP_PROG_F12MUL_WIRE : ZKP_PROG_F12MUL_STATE, n, n, 1, nullptr, last ? wire_out : nullptr,
+                              nullptr, nullptr)) != hipSuccess)
+                return e;
+        }
+    }
+    return hipSuccess;
 }
 
 // Run `body(pipe, base, n)` for every chunk of the batch, round-robin over the pipelines.  The caller's
@@ -908,7 +940,8 @@ static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lin
     // workspace first: hipMalloc/hipFree synchronise the device, so never (re)allocate between launches
     size_t cmax = n_total < chunk ? n_total : chunk;
     for (int i = 0; i < pipes; i++) {
-        if (need_lines && (e = ensure_buf(&d->pipe[i].lines, &d->pipe[i].lines_bytes, (size_t)NLINES * k * 6 * cmax * 64)) != hipSuccess) return e;
+        const size_t kg = k < MAX_GROUP ? k : MAX_GROUP;
+        if (need_lines && (e = ensure_buf(&d->pipe[i].lines, &d->pipe[i].lines_bytes, (size_t)NLINES * kg * 6 * cmax * 64)) != hipSuccess) return e;
         if ((e = ensure_buf(&d->pipe[i].state, &d->pipe[i].state_bytes, (size_t)ST_SIZE * cmax * 64)) != hipSuccess) return e;
     }
     if ((e = hipEventRecord(d->ready, s)) != hipSuccess) return e;
@@ -929,12 +962,9 @@ static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lin
 hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
                        uint64_t* out, hipStream_t s) {
     CoopDev* d = (CoopDev*)st->d_prog;
-    int prog = miller_prog(k, true);
-    if (prog < 0) return hipErrorNotSupported;
+    if (!coop_supports_k(k)) return hipErrorNotSupported;
     return for_chunks(d, n_checks, k, true, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
-        hipError_t e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k);
-        if (e != hipSuccess) return e;
-        return run_prog(d, pp, prog, n, n, (uint32_t)k, nullptr, out + 72 * base, nullptr, nullptr);
+        return miller_on_pipe(d, pp, g1, g2, i1, i2, base, n, k, out + 72 * base);
     });
 }
 
@@ -957,12 +987,10 @@ hipError_t coop_final_exp(CoopState* st, const uint64_t* f, size_t n_total, uint
 hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
                         uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s) {
     CoopDev* d = (CoopDev*)st->d_prog;
-    int prog = miller_prog(k, false);
-    if (prog < 0) return hipErrorNotSupported;
+    if (!coop_supports_k(k)) return hipErrorNotSupported;
     return for_chunks(d, n_checks, k, true, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
-        hipError_t e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k);
+        hipError_t e = miller_on_pipe(d, pp, g1, g2, i1, i2, base, n, k, nullptr);
         if (e != hipSuccess) return e;
-        if ((e = run_prog(d, pp, prog, n, n, (uint32_t)k, nullptr, nullptr, nullptr, nullptr)) != hipSuccess) return e;
         if ((e = run_prog(d, pp, ZKP_PROG_FEXP_A_STATE, n, n, 1, nullptr, nullptr, nullptr, nullptr)) != hipSuccess) return e;
         return fexp_tail(d, pp, n, out_gt ? out_gt + 72 * base : nullptr, ok ? ok + base : nullptr, all_ok);
     });
