@@ -88,6 +88,17 @@ int zkp_final_exponentiation_batch(zkp_ctx* ctx, const uint64_t* f, size_t n, ui
  * *all_ok = AND over this call's checks (the cross-GPU AND is the caller's single RCCL all-reduce). */
 int zkp_pairing_check_batch(zkp_ctx* ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1,
                             const uint8_t* inf2, size_t n_checks, size_t k, uint8_t* ok, int* all_ok);
+/* ---- the whole batch as ONE product check (SURVEY.md 8e variant; BLS batch verification shape) ----
+ * multi_miller_loop(&[(P_0,Q_0) .. (P_n-1,Q_n-1)]) over ALL n pairs -> one Fp12 (72 u64); n == 0 gives one.
+ * A multi-GPU host multiplies the per-GPU values (all-gather of 576 B per rank, zkp_fp12_product) and runs
+ * ONE zkp_final_exponentiation_batch(n = 1). */
+int zkp_miller_product(zkp_ctx* ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
+                       size_t n, uint64_t* out_ml);
+/* out = f_0 * f_1 * ... * f_n-1 (Fp12 Mul, reference src/fp12.rs:193-210, folded by a log-depth tree); n == 0 gives one. */
+int zkp_fp12_product(zkp_ctx* ctx, const uint64_t* f, size_t n, uint64_t* out);
+/* *is_one = (final_exponentiation(zkp_miller_product(..)) == Gt::identity()); out_gt (72 u64) may be NULL. */
+int zkp_pairing_product_check(zkp_ctx* ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1,
+                              const uint8_t* inf2, size_t n, uint64_t* out_gt, int* is_one);
 /* status[i]: 0 valid (or infinity), 1 not on curve, 2 not torsion free. */
 int zkp_g1_is_valid_batch(zkp_ctx* ctx, const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* status);
 int zkp_g2_is_valid_batch(zkp_ctx* ctx, const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status);
@@ -126,6 +137,13 @@ int zkp_pairing_check_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2
 int zkp_pairing_gt_check_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1,
                                    const void* d_inf2, size_t n_checks, size_t k, void* d_out_gt, void* d_ok,
                                    void* d_all_ok, void* stream);
+/* device flavours of the one-product-check entry points; d_out_ml / d_out: 72 u64; d_out_gt (may be NULL): 72 u64;
+ * d_is_one (may be NULL): one int32. */
+int zkp_miller_product_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1, const void* d_inf2,
+                           size_t n, void* d_out_ml, void* stream);
+int zkp_fp12_product_dev(zkp_ctx* ctx, const void* d_f, size_t n, void* d_out, void* stream);
+int zkp_pairing_product_check_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1,
+                                  const void* d_inf2, size_t n, void* d_out_gt, void* d_is_one, void* stream);
 int zkp_g1_is_valid_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_inf, size_t n, void* d_status, void* stream);
 int zkp_g2_is_valid_batch_dev(zkp_ctx* ctx, const void* d_g2, const void* d_inf, size_t n, void* d_status, void* stream);
 int zkp_g1_mul_batch_dev(zkp_ctx* ctx, const void* d_base, size_t base_stride, const void* d_scalars, size_t n,

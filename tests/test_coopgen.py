@@ -76,6 +76,20 @@ def test_grouped_miller_join_matches_single_loop(model_vectors):
     assert [cg.from_mont(es.state[cg.ST_F + i]) for i in range(12)] == [H(x) for x in c["miller"]]
 
 
+def test_fp12_product_tree_level(model_vectors):
+    """one level of the Fp12 product tree: wire x wire -> wire"""
+    H = lambda s: int(s, 16)
+    c = model_vectors["pairing"]["multi3"]
+    a = [H(x) for x in c["miller"]]
+    g = m.f12_flat_ints(m.multi_miller_loop([(m.G1_GEN, m.G2_GEN)]))
+    em = cg.Emu(wire_in=a, wire_in2=g).run(cg.prog_f12mul_pairs().steps)
+    assert em.wire_out == m.f12_flat_ints(m.f12_mul(m.f12_from_flat_ints(a), m.f12_from_flat_ints(g)))
+    # x * 1 == x either way
+    one = [1] + [0] * 11
+    assert cg.Emu(wire_in=a, wire_in2=one).run(cg.prog_f12mul_pairs().steps).wire_out == a
+    assert cg.Emu(wire_in=one, wire_in2=g).run(cg.prog_f12mul_pairs().steps).wire_out == g
+
+
 def test_program_encoding_is_consistent():
     for name, mk in cg.PROGRAMS.items():
         b = mk()

@@ -51,6 +51,44 @@ def test_sharded_and_reduce_gloo(bad_check):
     assert t0 == t1 == 2.0                                  # max over ranks
 
 
+def _worker_product(rank, ws, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from zkvm_pairings_amd import dist as zd
+
+    def miller_product_fn(lo, hi):       # stand-in for engine.miller_product: a recognisable 72-word record
+        return torch.arange(72, dtype=torch.int64) * 1000 + lo * 7 + hi
+
+    def finish_fn(parts):
+        q.put((rank, parts.tolist()))
+        return parts.shape == (ws, 72)
+
+    res = zd.sharded_product_check(miller_product_fn, finish_fn, 1001)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_product_check_gathers_every_rank_part_gloo():
+    ws = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_product, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2 * ws)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [[j * 1000 + lo * 7 + hi for j in range(72)] for lo, hi in ((0, 501), (501, 1001))]
+    parts = [v for _, v in got if isinstance(v, list)]
+    flags = [v for _, v in got if isinstance(v, bool)]
+    assert parts == [want, want] and flags == [True, True]      # both ranks see both parts, in rank order
+
+
 def test_shard_range_partitions():
     from zkvm_pairings_amd.dist import shard_range
     for n in (0, 1, 7, 8, 1 << 20, (1 << 20) + 5):

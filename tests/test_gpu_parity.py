@@ -304,6 +304,65 @@ def test_pairing_check_many_pairs_per_check(keng, k, monkeypatch):
         e.close()
 
 
+def test_fp12_product_and_one_product_check(keng):
+    """the whole batch as ONE check: Miller product over all pairs (groups of four + product tree), Fp12
+    product tree on its own, one shared final exponentiation; host and device entry points; odd sizes."""
+    import torch
+    from zkvm_pairings_amd import synthetic
+    n = 203                                   # 50 groups of four + a group of three; tree sizes 51, 26, 13, 7, 4, 2
+    g1, g2, _, _ = synthetic.random_pairs(keng, n, seed=909)
+    inf1 = np.zeros(n, dtype=np.uint8)
+    inf1[[0, 77, 202]] = 1
+    want_ml = o.multi_miller_loop_batch(g1, g2, 1, n, inf1, None)[0]
+    got_ml = keng.miller_product(g1, g2, inf1, None)
+    assert np.array_equal(got_ml, want_ml)
+    # Fp12 product tree against a left fold of the oracle's Fp12 multiplication
+    vals = o.multi_miller_loop_batch(g1[:37], g2[:37], 37, 1)
+    acc = o.fp12_one()
+    for v in vals:
+        acc = o.fp12_mul(acc, v)
+    for m_ in (37, 1, 2, 3):
+        a = o.fp12_one()
+        for v in vals[:m_]:
+            a = o.fp12_mul(a, v)
+        assert np.array_equal(keng.fp12_product(vals[:m_]), a)
+    assert np.array_equal(keng.fp12_product(vals[:0]), o.fp12_one())
+    assert np.array_equal(keng.miller_product(g1[:0], g2[:0]), o.fp12_one())
+    # one final exponentiation for the whole batch
+    gt, is_one = keng.pairing_product_check(g1, g2, inf1, None)
+    assert np.array_equal(gt, o.final_exponentiation_batch(want_ml[None])[0]) and not is_one
+    # cancelling batch: (P_i, Q_i), (-P_i, Q_i) interleaved -> the product is one
+    neg = g1.copy()
+    for j in range(n):
+        neg[j, 6:] = o.to_limbs((m.P - o.from_limbs(g1[j, 6:])) % m.P)
+    G1 = np.concatenate([g1, neg])
+    G2 = np.concatenate([g2, g2])
+    gt, is_one = keng.pairing_product_check(G1, G2)
+    assert is_one and np.array_equal(gt, keng.gt_identity())
+    gt, is_one = keng.pairing_product_check(G1[:-1], G2[:-1])
+    assert not is_one
+    gt, is_one = keng.pairing_product_check(G1[:0], G2[:0])
+    assert is_one
+    # device-resident flavour
+    dev = torch.device("cuda", 0)
+    t1 = torch.from_numpy(G1.view(np.int64)).to(dev)
+    t2 = torch.from_numpy(G2.view(np.int64)).to(dev)
+    gt_t, one_t = keng.pairing_product_check(t1, t2)
+    assert int(one_t.item()) == 1 and np.array_equal(gt_t.cpu().numpy().view(np.uint64), keng.gt_identity())
+    ml_t = keng.miller_product(t1[:n].contiguous(), t2[:n].contiguous())
+    assert np.array_equal(ml_t.cpu().numpy().view(np.uint64), o.multi_miller_loop_batch(g1, g2, 1, n)[0])
+    # the multi-GPU composition on one rank: shard products -> gathered parts -> product -> one final exponentiation
+    from zkvm_pairings_amd import dist as zd
+    parts = torch.stack([keng.miller_product(t1[:150].contiguous(), t2[:150].contiguous()),
+                         keng.miller_product(t1[150:].contiguous(), t2[150:].contiguous())])
+    fin = keng.final_exponentiation(keng.fp12_product(parts).reshape(1, 72))
+    assert np.array_equal(fin.cpu().numpy().view(np.uint64)[0], keng.gt_identity())
+    res = zd.sharded_product_check(lambda lo, hi: keng.miller_product(t1[lo:hi].contiguous(), t2[lo:hi].contiguous()),
+                                   lambda ps: np.array_equal(keng.final_exponentiation(keng.fp12_product(ps.contiguous()).reshape(1, 72))
+                                                             .cpu().numpy().view(np.uint64)[0], keng.gt_identity()), 2 * n)
+    assert res is True
+
+
 def test_config2_full_batch_bit_exact(eng):
     """BASELINE.json config 2: 2^16 random (G1,G2) pairs on one GPU, EVERY Gt compared with the CPU oracle."""
     import hashlib

@@ -50,6 +50,14 @@ for kern in ("coop", "thread"):
     dt = timed(lambda: eng.pairing_gt_check(g1k, g2k, 8, None, ok8, flag))
     out["check8_%s_checks_per_s" % kern] = n8 / dt
 del g1k, g2k
+# the whole batch as ONE product check: Miller loops four pairs per accumulator, Fp12 product tree, one final exponentiation
+np_ = 4 * n
+g1p, g2p, _, _ = synthetic.random_pairs(eng, np_, seed=9, device_tensors=True)
+for kern in ("coop", "thread"):
+    eng.set_kernel(kern)
+    dt = timed(lambda: eng.pairing_product_check(g1p, g2p))
+    out["product_check_%s_pairs_per_s" % kern] = np_ / dt
+del g1p, g2p
 eng.set_kernel("auto")
 p1, p2 = g1[:n].contiguous(), g2[:n].contiguous()
 dt = timed(lambda: eng.g1_is_valid(p1))

@@ -57,7 +57,7 @@ CONST_BASE = 64
 
 OP_END, OP_MULACC, OP_LIN, OP_GLOAD, OP_GSTORE, OP_LOOP, OP_ENDLOOP = 0, 1, 2, 3, 4, 5, 6
 # GLOAD / GSTORE address kinds
-K_LINE, K_STATE, K_WIRE = 0, 1, 2
+K_LINE, K_STATE, K_WIRE, K_WIRE2 = 0, 1, 2, 3   # K_WIRE2: wire record of check + chk_off (tree reductions)
 
 
 # ------------------------------------------------------------------------------------------ constants region
@@ -640,6 +640,19 @@ def prog_f12mul(to_wire):
     return b
 
 
+def prog_f12mul_pairs():
+    """wire[check] <- wire[check] * wire[check + chk_off]: one level of the tree that multiplies n Fp12 values
+    (product of Miller values before ONE shared final exponentiation)."""
+    b = Builder()
+    f = load_input(b, True)
+    g = load_input(b, True, wire_kind=K_WIRE2)
+    h = b.fp12_mul(f, f, g)
+    raw1 = Lin.of(CONST_SLOT["RAW_ONE"])
+    b.mulacc([{"dst": g.slots[i], "bil": Bil([(h.lin(i), raw1, 1)])} for i in range(12)])
+    b.gstore(K_WIRE, [(g.slots[i], i) for i in range(12)])
+    return b
+
+
 def finish_output(b, v, to_wire, state_base, check_identity=False):
     t = b.alloc(12)
     if to_wire:
@@ -653,10 +666,10 @@ def finish_output(b, v, to_wire, state_base, check_identity=False):
     b.release(t)
 
 
-def load_input(b, from_wire, state_base=0):
+def load_input(b, from_wire, state_base=0, wire_kind=K_WIRE):
     f = b.alloc12()
     if from_wire:
-        b.gload(K_WIRE, [(f.slots[i], i) for i in range(12)])
+        b.gload(wire_kind, [(f.slots[i], i) for i in range(12)])
         r2 = Lin.of(CONST_SLOT["RAW_R2"])
         b.mulacc([{"dst": f.slots[i], "bil": Bil([(f.lin(i), r2, 1)])} for i in range(12)])
     else:
@@ -938,7 +951,7 @@ class Emu:
     """one lane-group.  slots hold limb vectors.  `lines`: list of steps, each a list (per pair) of 6
     true field values (c2, c1*xP, c0*yP); `state`/`wire_in`: dict/list of true values."""
 
-    def __init__(self, lines=None, state=None, wire_in=None):
+    def __init__(self, lines=None, state=None, wire_in=None, wire_in2=None):
         self.slot = {}
         for name, val in CONSTS:
             self.slot[CONST_SLOT[name]] = const_limbs(name, val)
@@ -946,6 +959,7 @@ class Emu:
         self.cursor = 0
         self.state = dict(state or {})     # element -> limb vector
         self.wire_in = wire_in
+        self.wire_in2 = wire_in2
         self.wire_out = None
         self.is_identity = None
         self.max_col = 0
@@ -1015,7 +1029,7 @@ class Emu:
                     elif st["kind"] == K_STATE:
                         self.slot[dst] = list(self.state[idx])
                     else:
-                        v = self.wire_in[idx]
+                        v = (self.wire_in2 if st["kind"] == K_WIRE2 else self.wire_in)[idx]
                         assert 0 <= v < P
                         self.slot[dst] = [(v >> (W * i)) & ((1 << W) - 1) for i in range(NL)]
                 self.cursor += st.get("advance", 0)
@@ -1175,6 +1189,7 @@ PROGRAMS = {
     "miller3_wire": lambda: prog_miller(3, True),
     "miller4_state": lambda: prog_miller(4, False),
     "miller4_wire": lambda: prog_miller(4, True),
+    "f12mul_pairs": prog_f12mul_pairs,
     "f12mul_state": lambda: prog_f12mul(False),
     "f12mul_wire": lambda: prog_f12mul(True),
     "fexp_a_state": lambda: prog_fexp_a(False),

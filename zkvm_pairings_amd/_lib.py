@@ -29,6 +29,9 @@ SIGNATURES = {
     "zkp_multi_miller_loop_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp]),
     "zkp_final_exponentiation_batch": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "zkp_pairing_check_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, ctypes.POINTER(c_int)]),
+    "zkp_miller_product": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "zkp_fp12_product": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "zkp_pairing_product_check": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, ctypes.POINTER(c_int)]),
     "zkp_g1_is_valid_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "zkp_g2_is_valid_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "zkp_g1_mul_batch": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp, c_vp]),
@@ -43,6 +46,9 @@ SIGNATURES = {
     "zkp_final_exponentiation_batch_dev": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
     "zkp_pairing_check_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, c_vp, c_vp]),
     "zkp_pairing_gt_check_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, c_vp, c_vp, c_vp]),
+    "zkp_miller_product_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "zkp_fp12_product_dev": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "zkp_pairing_product_check_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
     "zkp_g1_is_valid_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp]),
     "zkp_g2_is_valid_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp]),
     "zkp_g1_mul_batch_dev": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp, c_vp, c_vp]),

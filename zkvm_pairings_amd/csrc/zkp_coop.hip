@@ -35,7 +35,7 @@ constexpr int ST_SIZE = ZKP_COOP_ST_SIZE;
 constexpr int NLINES = ZKP_COOP_NLINES;
 
 enum { OP_END = 0, OP_MULACC = 1, OP_LIN = 2, OP_GLOAD = 3, OP_GSTORE = 4, OP_LOOP = 5, OP_ENDLOOP = 6 };
-enum { K_LINE = 0, K_STATE = 1, K_WIRE = 2 };
+enum { K_LINE = 0, K_STATE = 1, K_WIRE = 2, K_WIRE2 = 3 };   // K_WIRE2: wire record of check + chk_off
 
 __device__ __constant__ const int32_t K_PBAL[NL] = {ZKP_COOP_P_BAL};
 
@@ -55,6 +55,7 @@ struct CoopArgs {
     uint32_t S;               // LDS plane stride (int4) of a group region (= the program's slot count)
     uint32_t nconst;          // constants the program references (prefix of the table)
     uint32_t st_off;          // added to every K_STATE element index (where a group's Miller value lands)
+    uint32_t chk_off;         // K_WIRE2 loads read the wire record of check + chk_off (product tree)
 };
 
 // ---- LDS access: quad-plane SoA, record = 4 x int4 at off, off+S, off+2S, off+3S
@@ -226,8 +227,8 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             const uint32_t idx = w >> 8;
             if (active && ((w >> 7) & 1)) {
                 int32_t x[NL];
-                if (arg == K_WIRE) {
-                    const uint64_t* src = A.wire_in + (size_t)check * 72 + idx * 6;
+                if (arg == K_WIRE || arg == K_WIRE2) {
+                    const uint64_t* src = A.wire_in + ((size_t)check + (arg == K_WIRE2 ? A.chk_off : 0u)) * 72 + idx * 6;
                     uint64_t ww[6];
 #pragma unroll
                     for (int i = 0; i < 6; i++) ww[i] = src[i];
@@ -850,7 +851,7 @@ static hipError_t ensure_buf(int4** p, size_t* cap, size_t bytes) {
 }
 
 static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks, uint32_t nc, uint32_t k, const uint64_t* wire_in,
-                           uint64_t* wire_out, uint8_t* ok, int* all_ok, uint32_t st_off = 0) {
+                           uint64_t* wire_out, uint8_t* ok, int* all_ok, uint32_t st_off = 0, uint32_t chk_off = 0) {
     hipStream_t s = pp->stream;
     CoopArgs a;
     a.hdr = d->progs[prog].hdr;
@@ -869,6 +870,7 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     a.S = ZKP_COOP_NSLOT;
     a.nconst = d->progs[prog].nconst;
     a.st_off = st_off;
+    a.chk_off = chk_off;
     size_t lds_bytes = (size_t)(4 * ZKP_COOP_NCONST + GROUPS * (4 * ZKP_COOP_NSLOT + 3)) * 16;
     static const char* pad_env = getenv("ZKP_COOP_LDS_PAD");   // occupancy experiments only
     if (pad_env) lds_bytes += (size_t)atol(pad_env);
@@ -975,13 +977,22 @@ static hipError_t fexp_tail(CoopDev* d, CoopPipe* pp, uint32_t n, uint64_t* out,
     return run_prog(d, pp, ZKP_PROG_FEXP_C, n, n, 1, nullptr, out, ok, all_ok);
 }
 
-hipError_t coop_final_exp(CoopState* st, const uint64_t* f, size_t n_total, uint64_t* out, hipStream_t s) {
+hipError_t coop_final_exp(CoopState* st, const uint64_t* f, size_t n_total, uint64_t* out, uint8_t* ok, int* all_ok, hipStream_t s) {
     CoopDev* d = (CoopDev*)st->d_prog;
     return for_chunks(d, n_total, 1, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
         hipError_t e = run_prog(d, pp, ZKP_PROG_FEXP_A_WIRE, n, n, 1, f + 72 * base, nullptr, nullptr, nullptr);
         if (e != hipSuccess) return e;
-        return fexp_tail(d, pp, n, out + 72 * base, nullptr, nullptr);
+        return fexp_tail(d, pp, n, out ? out + 72 * base : nullptr, ok ? ok + base : nullptr, all_ok);
     });
+}
+
+// one level of the Fp12 product tree, in place: buf[c] <- buf[c] * buf[c + h] for c < m  (m <= h)
+hipError_t coop_fp12_mul_pairs(CoopState* st, uint64_t* buf, size_t m, size_t h, hipStream_t s) {
+    CoopDev* d = (CoopDev*)st->d_prog;
+    if (m > 0xffffffffu || h > 0xffffffffu) return hipErrorInvalidValue;
+    CoopPipe on_s = d->pipe[0];   // no workspace is touched: only the stream matters
+    on_s.stream = s;
+    return run_prog(d, &on_s, ZKP_PROG_F12MUL_PAIRS, (uint32_t)m, (uint32_t)m, 1, buf, buf, nullptr, nullptr, 0, (uint32_t)h);
 }
 
 hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,

@@ -19,7 +19,7 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop);
 void coop_free(CoopState* st);
 // true when `kind` (zkp_kernel_kind) routes the pairing path through the cooperative kernels
 bool coop_selected(const CoopState* st, int kind);
-// lane-cooperative programs exist for 1..4 pairs per check; other k use the thread family
+// pairs per check the cooperative path takes (checks with more than four pairs run in groups of four)
 bool coop_supports_k(size_t k);
 // test hook: 28-bit-limb Montgomery multiply on wire operands
 hipError_t coop_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, hipStream_t s);
@@ -31,7 +31,10 @@ hipError_t coop_g2_mul(const uint64_t* base, size_t stride, const uint64_t* sc, 
 hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, float* ms);
 hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks,
                        size_t k, uint64_t* out, hipStream_t s);
-hipError_t coop_final_exp(CoopState* st, const uint64_t* f, size_t n, uint64_t* out, hipStream_t s);
+// out (wire Gt), ok (per element Gt == identity) and all_ok (AND-ed into *all_ok) are each optional
+hipError_t coop_final_exp(CoopState* st, const uint64_t* f, size_t n, uint64_t* out, uint8_t* ok, int* all_ok, hipStream_t s);
+// one level of the Fp12 product tree, in place on wire records: buf[c] <- buf[c] * buf[c + h] for c < m
+hipError_t coop_fp12_mul_pairs(CoopState* st, uint64_t* buf, size_t m, size_t h, hipStream_t s);
 hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks,
                         size_t k, uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s);
 

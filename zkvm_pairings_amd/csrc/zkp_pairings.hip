@@ -113,6 +113,25 @@ __global__ void __launch_bounds__(TPB) k_pairing(const uint64_t* g1, const uint6
 
 __global__ void k_set_int(int* p, int v) { *p = v; }
 
+// one level of the Fp12 product tree, in place on wire records: buf[c] <- buf[c] * buf[c + h], c < m
+__global__ void __launch_bounds__(TPB) k_fp12_mul_pairs(uint64_t* buf, size_t m, size_t h) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= m) return;
+    Fp12 a, b;
+    fp12_load(&a, buf + 72 * i);
+    fp12_load(&b, buf + 72 * (i + h));
+    fp12_mul(&a, &a, &b);
+    fp12_store(buf + 72 * i, &a);
+}
+
+// *is_one = (gt == Gt::identity()) on a canonical wire record
+__global__ void k_gt_is_one(const uint64_t* gt, int* is_one) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t d = gt[0] ^ 1ull;
+    for (int i = 1; i < 72; i++) d |= gt[i];
+    *is_one = d == 0 ? 1 : 0;
+}
+
 // reference src/g1.rs:49-62: 0 ok / 1 not on curve / 2 not torsion free
 __global__ void __launch_bounds__(TPB) k_g1_valid(const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* status) {
     size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
@@ -284,6 +303,8 @@ struct zkp_ctx {
     void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int* d_flag = nullptr;
+    uint64_t* prod = nullptr;   // Fp12 records of the product tree (zkp_fp12_product / zkp_miller_product)
+    size_t prod_cap = 0;
     hipDeviceProp_t prop;
     zkp::CoopState coop;
 };
@@ -329,7 +350,7 @@ int miller_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t
 int final_exp_dev(zkp_ctx* c, const uint64_t* f, size_t n, uint64_t* out, hipStream_t s) {
     if (n == 0) return ZKP_OK;
     if (zkp::coop_selected(&c->coop, c->kernel))
-        return zkp::coop_final_exp(&c->coop, f, n, out, s) == hipSuccess ? ZKP_OK : (c->err = "coop_final_exp launch failed", ZKP_ERR_HIP);
+        return zkp::coop_final_exp(&c->coop, f, n, out, nullptr, nullptr, s) == hipSuccess ? ZKP_OK : (c->err = "coop_final_exp launch failed", ZKP_ERR_HIP);
     hipLaunchKernelGGL(k_final_exp, dim3(grid_for(n, TPB)), dim3(TPB), 0, s, f, n, out);
     HIPCHK(c, hipGetLastError());
     return ZKP_OK;
@@ -345,6 +366,76 @@ int pairing_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_
         return zkp::coop_pairing(&c->coop, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok, s) == hipSuccess ? ZKP_OK : (c->err = "coop_pairing launch failed", ZKP_ERR_HIP);
     hipLaunchKernelGGL(k_pairing, dim3(grid_for(n_checks, TPB)), dim3(TPB), 0, s, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok);
     HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
+}
+
+int ensure_prod(zkp_ctx* c, size_t records) {
+    const size_t bytes = (records + 2) * 576;   // two spare records: product and Gt of zkp_pairing_product_check
+    if (bytes <= c->prod_cap) return ZKP_OK;
+    if (c->prod) { HIPCHK(c, hipFree(c->prod)); c->prod = nullptr; c->prod_cap = 0; }
+    HIPCHK(c, hipMalloc((void**)&c->prod, bytes));
+    c->prod_cap = bytes;
+    return ZKP_OK;
+}
+
+// buf[0] <- prod_{i<n} buf[i] (n >= 1), destroying buf[1..n): ceil(log2 n) launches, level l multiplies element c
+// by element c + ceil(n_l / 2)
+int fp12_product_inplace(zkp_ctx* c, uint64_t* buf, size_t n, hipStream_t s) {
+    const bool coop = zkp::coop_selected(&c->coop, c->kernel);
+    while (n > 1) {
+        const size_t h = (n + 1) / 2, m = n - h;
+        if (coop) {
+            if (zkp::coop_fp12_mul_pairs(&c->coop, buf, m, h, s) != hipSuccess) { c->err = "coop_fp12_mul_pairs launch failed"; return ZKP_ERR_HIP; }
+        } else {
+            hipLaunchKernelGGL(k_fp12_mul_pairs, dim3(grid_for(m, TPB)), dim3(TPB), 0, s, buf, m, h);
+            HIPCHK(c, hipGetLastError());
+        }
+        n = h;
+    }
+    return ZKP_OK;
+}
+
+int fp12_product_dev(zkp_ctx* c, const uint64_t* f, size_t n, uint64_t* out, hipStream_t s) {
+    if (n == 0) { HIPCHK(c, hipMemcpyAsync(out, GT_IDENTITY, 576, hipMemcpyHostToDevice, s)); return ZKP_OK; }
+    int rc = ensure_prod(c, n);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->prod, f, n * 576, hipMemcpyDeviceToDevice, s));
+    if ((rc = fp12_product_inplace(c, c->prod, n, s))) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->prod, 576, hipMemcpyDeviceToDevice, s));
+    return ZKP_OK;
+}
+
+// multi_miller_loop over the whole batch as ONE check: the pairs are taken four at a time (one shared accumulator
+// per four pairs), the n/4 values are multiplied by the product tree.  Result left in c->prod[0..72) and copied to out.
+int miller_product_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n, uint64_t* out,
+                       hipStream_t s) {
+    if (n == 0) { HIPCHK(c, hipMemcpyAsync(out, GT_IDENTITY, 576, hipMemcpyHostToDevice, s)); return ZKP_OK; }
+    const size_t n4 = n / 4, r = n % 4, nv = n4 + (r ? 1 : 0);
+    int rc = ensure_prod(c, nv);
+    if (rc) return rc;
+    if (n4 && (rc = miller_dev(c, g1, g2, i1, i2, n4, 4, c->prod, s))) return rc;
+    if (r && (rc = miller_dev(c, g1 + 12 * 4 * n4, g2 + 24 * 4 * n4, i1 ? i1 + 4 * n4 : nullptr, i2 ? i2 + 4 * n4 : nullptr, 1, r,
+                              c->prod + 72 * n4, s)))
+        return rc;
+    if ((rc = fp12_product_inplace(c, c->prod, nv, s))) return rc;
+    if (out) HIPCHK(c, hipMemcpyAsync(out, c->prod, 576, hipMemcpyDeviceToDevice, s));
+    return ZKP_OK;
+}
+
+// prod_i e(P_i, Q_i) == Gt::identity() with ONE final exponentiation; out_gt and is_one are device pointers, each optional
+int product_check_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n, uint64_t* out_gt,
+                      int* is_one, hipStream_t s) {
+    int rc = ensure_prod(c, n / 4 + 1);
+    if (rc) return rc;
+    if ((rc = miller_product_dev(c, g1, g2, i1, i2, n, n ? nullptr : c->prod, s))) return rc;
+    const size_t nv = n / 4 + (n % 4 ? 1 : 0);
+    uint64_t* gt = c->prod + 72 * (nv + 1);      // spare record (ensure_prod keeps two)
+    if ((rc = final_exp_dev(c, c->prod, 1, gt, s))) return rc;
+    if (out_gt) HIPCHK(c, hipMemcpyAsync(out_gt, gt, 576, hipMemcpyDeviceToDevice, s));
+    if (is_one) {
+        hipLaunchKernelGGL(k_gt_is_one, dim3(1), dim3(64), 0, s, gt, is_one);
+        HIPCHK(c, hipGetLastError());
+    }
     return ZKP_OK;
 }
 
@@ -441,6 +532,7 @@ void zkp_free(zkp_ctx* c) {
     for (int i = 0; i < 8; i++)
         if (c->buf[i]) (void)hipFree(c->buf[i]);
     if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->prod) (void)hipFree(c->prod);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -483,6 +575,26 @@ int zkp_final_exponentiation_batch_dev(zkp_ctx* c, const void* f, size_t n, void
     int rc = bind(c);
     if (rc) return rc;
     return final_exp_dev(c, (const uint64_t*)f, n, (uint64_t*)out, S(stream));
+}
+int zkp_fp12_product_dev(zkp_ctx* c, const void* f, size_t n, void* out, void* stream) {
+    if (!c || !out || (n && !f) || n > 0x7fffffffu) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    return fp12_product_dev(c, (const uint64_t*)f, n, (uint64_t*)out, S(stream));
+}
+int zkp_miller_product_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n, void* out_ml, void* stream) {
+    if (!c || !out_ml || (n && (!g1 || !g2)) || n > 0x7fffffffu) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    return miller_product_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n, (uint64_t*)out_ml, S(stream));
+}
+int zkp_pairing_product_check_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n, void* out_gt,
+                                  void* is_one, void* stream) {
+    if (!c || (n && (!g1 || !g2)) || n > 0x7fffffffu) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    return product_check_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n, (uint64_t*)out_gt, (int*)is_one,
+                             S(stream));
 }
 int zkp_pairing_check_batch_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n_checks, size_t k,
                                 void* ok, void* all_ok, void* stream) {
@@ -591,6 +703,52 @@ int zkp_final_exponentiation_batch(zkp_ctx* c, const uint64_t* f, size_t n, uint
     if ((rc = final_exp_dev(c, (const uint64_t*)c->buf[5], n, (uint64_t*)c->buf[4], c->stream))) return rc;
     HIPCHK(c, hipMemcpyAsync(out_gt, c->buf[4], n * 576, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZKP_OK;
+}
+int zkp_fp12_product(zkp_ctx* c, const uint64_t* f, size_t n, uint64_t* out) {
+    if (!c || !out || (n && !f) || n > 0x7fffffffu) return ZKP_ERR_ARG;
+    if (!n) { memcpy(out, GT_IDENTITY, 576); return ZKP_OK; }
+    int rc = bind(c);
+    if (rc) return rc;
+    if ((rc = ensure_prod(c, n))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->prod, f, n * 576, hipMemcpyHostToDevice, c->stream));
+    if ((rc = validate_dev(c, c->prod, n * 12))) return rc;
+    if ((rc = fp12_product_inplace(c, c->prod, n, c->stream))) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->prod, 576, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZKP_OK;
+}
+int zkp_miller_product(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n, uint64_t* out_ml) {
+    if (!c || !out_ml || (n && (!g1 || !g2)) || n > 0x7fffffffu) return ZKP_ERR_ARG;
+    if (!n) { memcpy(out_ml, GT_IDENTITY, 576); return ZKP_OK; }
+    int rc = bind(c);
+    if (rc) return rc;
+    Staged st = {nullptr, nullptr, nullptr, nullptr};
+    if ((rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st))) return rc;
+    if ((rc = miller_product_dev(c, st.g1, st.g2, st.i1, st.i2, n, nullptr, c->stream))) return rc;
+    HIPCHK(c, hipMemcpyAsync(out_ml, c->prod, 576, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZKP_OK;
+}
+int zkp_pairing_product_check(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n,
+                              uint64_t* out_gt, int* is_one) {
+    if (!c || (n && (!g1 || !g2)) || n > 0x7fffffffu) return ZKP_ERR_ARG;
+    if (!n) {
+        if (out_gt) memcpy(out_gt, GT_IDENTITY, 576);
+        if (is_one) *is_one = 1;
+        return ZKP_OK;
+    }
+    int rc = bind(c);
+    if (rc) return rc;
+    Staged st = {nullptr, nullptr, nullptr, nullptr};
+    if ((rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st))) return rc;
+    if ((rc = ensure(c, 4, 576))) return rc;
+    if ((rc = product_check_dev(c, st.g1, st.g2, st.i1, st.i2, n, (uint64_t*)c->buf[4], c->d_flag, c->stream))) return rc;
+    int one = 0;
+    if (out_gt) HIPCHK(c, hipMemcpyAsync(out_gt, c->buf[4], 576, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&one, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (is_one) *is_one = one;
     return ZKP_OK;
 }
 int zkp_pairing_check_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks,

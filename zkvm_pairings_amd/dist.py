@@ -2,7 +2,11 @@
 the CPU tests).  The pairing path shards embarrassingly - every pairing / k-pair check is
 independent - so the batch is split into contiguous blocks per rank and the ONLY
 collective is one all-reduce of the per-rank AND flag.  RCCL has no bitwise-AND reduction, so the
-AND of {0,1} flags is MIN.  Bulk data never crosses xGMI."""
+AND of {0,1} flags is MIN.  Bulk data never crosses xGMI.
+
+The ONE-product variant (prod over the WHOLE batch of e(P_i,Q_i) == 1, the BLS batch
+verification shape) has a real exchange step: every rank reduces its shard to one Fp12 Miller value,
+the ranks all-gather those 576-byte values, multiply them and run ONE final exponentiation."""
 import torch
 import torch.distributed as dist
 
@@ -46,3 +50,23 @@ def sharded_pairing_check(check_fn, n_checks, device):
         flag = torch.ones(1, dtype=torch.int32, device=device)
     and_reduce(flag)
     return bool(flag.item())
+
+
+def gather_parts(part):
+    """part: (72,) int64/uint64 tensor (this rank's Fp12 Miller product) -> (world, 72) on every rank.
+    One all_gather of 576 B per rank (latency bound; xGMI bandwidth is irrelevant)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        parts = [torch.empty_like(part) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, part.contiguous())
+        return torch.stack(parts)
+    return part.reshape(1, 72)
+
+
+def sharded_product_check(miller_product_fn, finish_fn, n_pairs):
+    """prod_{i < n_pairs} e(P_i, Q_i) == Gt::identity() over ranks.
+    miller_product_fn(lo, hi) -> (72,) tensor: Miller product of pairs [lo, hi) (engine.miller_product; the
+    empty range gives Fp12::one()); finish_fn(parts (world,72)) -> bool: final_exponentiation(prod parts) ==
+    identity (engine.fp12_product + engine.final_exponentiation).  Every rank returns the same bool."""
+    rank, ws = world()
+    lo, hi = shard_range(n_pairs, rank, ws)
+    return bool(finish_fn(gather_parts(miller_product_fn(lo, hi))))

@@ -125,6 +125,59 @@ class PairingEngine:
         self._chk(self._lib.zkp_pairing_check_batch(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n // k, k, _ptr(ok), ctypes.byref(allok)))
         return ok, bool(allok.value)
 
+    # ---- the whole batch as ONE product check (one shared final exponentiation)
+    def miller_product(self, g1, g2, inf1=None, inf2=None):
+        """multi_miller_loop over ALL pairs of the batch -> (72,) MillerLoopResult"""
+        if _is_torch(g1):
+            import torch
+            self._t_check(g1, 12), self._t_check(g2, 24)
+            out = torch.empty(72, dtype=g1.dtype, device=g1.device)
+            self._chk(self._lib.zkp_miller_product_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), g1.numel() // 12,
+                                                       self._tp(out), self._stream()))
+            return out
+        g1, g2 = _np(g1, 12), _np(g2, 24)
+        n = g1.shape[0]
+        assert g2.shape[0] == n
+        i1 = None if inf1 is None else _np(inf1, None, np.uint8)
+        i2 = None if inf2 is None else _np(inf2, None, np.uint8)
+        out = np.empty(72, dtype=np.uint64)
+        self._chk(self._lib.zkp_miller_product(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n, _ptr(out)))
+        return out
+
+    def fp12_product(self, f):
+        """f_0 * f_1 * ... * f_n-1 of (n,72) Fp12 values -> (72,)"""
+        if _is_torch(f):
+            import torch
+            self._t_check(f, 72)
+            out = torch.empty(72, dtype=f.dtype, device=f.device)
+            self._chk(self._lib.zkp_fp12_product_dev(self._h, self._tp(f), f.numel() // 72, self._tp(out), self._stream()))
+            return out
+        f = _np(f, 72)
+        out = np.empty(72, dtype=np.uint64)
+        self._chk(self._lib.zkp_fp12_product(self._h, _ptr(f), f.shape[0], _ptr(out)))
+        return out
+
+    def pairing_product_check(self, g1, g2, inf1=None, inf2=None):
+        """-> (Gt (72,), is_one): prod_i e(g1[i], g2[i]) == Gt::identity() with one final exponentiation.
+        Device tensors return (Gt tensor, int32 tensor(1,)) without synchronising."""
+        if _is_torch(g1):
+            import torch
+            self._t_check(g1, 12), self._t_check(g2, 24)
+            gt = torch.empty(72, dtype=g1.dtype, device=g1.device)
+            one = torch.empty(1, dtype=torch.int32, device=g1.device)
+            self._chk(self._lib.zkp_pairing_product_check_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), g1.numel() // 12,
+                                                              self._tp(gt), self._tp(one), self._stream()))
+            return gt, one
+        g1, g2 = _np(g1, 12), _np(g2, 24)
+        n = g1.shape[0]
+        assert g2.shape[0] == n
+        i1 = None if inf1 is None else _np(inf1, None, np.uint8)
+        i2 = None if inf2 is None else _np(inf2, None, np.uint8)
+        gt = np.empty(72, dtype=np.uint64)
+        one = ctypes.c_int(0)
+        self._chk(self._lib.zkp_pairing_product_check(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n, _ptr(gt), ctypes.byref(one)))
+        return gt, bool(one.value)
+
     def g1_is_valid(self, g1, inf=None):
         if _is_torch(g1):
             return self._valid_t(g1, inf, 1)
