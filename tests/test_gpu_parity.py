@@ -328,6 +328,9 @@ def test_fp12_product_and_one_product_check(keng):
         assert np.array_equal(keng.fp12_product(vals[:m_]), a)
     assert np.array_equal(keng.fp12_product(vals[:0]), o.fp12_one())
     assert np.array_equal(keng.miller_product(g1[:0], g2[:0]), o.fp12_one())
+    # multi_miller_loop with few checks and long term lists takes the same route inside the C ABI
+    assert np.array_equal(keng.multi_miller_loop(g1[:200], g2[:200], 100, inf1[:200], None),
+                          o.multi_miller_loop_batch(g1[:200], g2[:200], 2, 100, inf1[:200], None))
     # one final exponentiation for the whole batch
     gt, is_one = keng.pairing_product_check(g1, g2, inf1, None)
     assert np.array_equal(gt, o.final_exponentiation_batch(want_ml[None])[0]) and not is_one

@@ -338,9 +338,21 @@ int bind(zkp_ctx* c) {
 }
 
 // ---- device-pointer implementations (shared by both API flavours)
+int miller_product_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n, uint64_t* out,
+                       hipStream_t s);
 int miller_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
                uint64_t* out, hipStream_t s) {
     if (n_checks == 0) return ZKP_OK;
+    if (k >= 64 && n_checks <= 16) {
+        // few checks with long term lists: spread each check's pairs over the GPU (four per accumulator) and fold the
+        // values with the product tree, instead of walking the check's groups one after the other
+        for (size_t ck = 0; ck < n_checks; ck++) {
+            int rc = miller_product_dev(c, g1 + 12 * ck * k, g2 + 24 * ck * k, i1 ? i1 + ck * k : nullptr, i2 ? i2 + ck * k : nullptr, k,
+                                        out + 72 * ck, s);
+            if (rc) return rc;
+        }
+        return ZKP_OK;
+    }
     if (zkp::coop_selected(&c->coop, c->kernel) && zkp::coop_supports_k(k))
         return zkp::coop_miller(&c->coop, g1, g2, i1, i2, n_checks, k, out, s) == hipSuccess ? ZKP_OK : (c->err = "coop_miller launch failed", ZKP_ERR_HIP);
     hipLaunchKernelGGL(k_miller, dim3(grid_for(n_checks, TPB)), dim3(TPB), 0, s, g1, g2, i1, i2, n_checks, k, out);
