@@ -390,6 +390,7 @@ def test_chunk_and_group_boundaries(monkeypatch):
     from zkvm_pairings_amd import PairingEngine, synthetic
     monkeypatch.setenv("ZKP_COOP_CHUNK", "320")
     monkeypatch.setenv("ZKP_COOP_STREAMS", "3")
+    monkeypatch.setenv("ZKP_COOP_SUPER", "640")     # two-phase final exponentiation over two super-chunks (640 + 363)
     e = PairingEngine(0)
     try:
         g1, g2, _, _ = synthetic.random_pairs(e, 1003, seed=99)

@@ -50,7 +50,7 @@ struct CoopArgs {
     uint8_t* ok;              // may be null
     int* all_ok;              // may be null
     uint32_t n_checks;
-    uint32_t nc;              // record stride (>= n_checks)
+    uint32_t nc;              // record stride of the state buffer (>= n_checks: a super-chunk's state is shared by its chunks)
     uint32_t k;
     uint32_t S;               // LDS plane stride (int4) of a group region (= the program's slot count)
     uint32_t nconst;          // constants the program references (prefix of the table)
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                     }
                 } else {
                     size_t rec;
-                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + idx) * A.nc + check;
+                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + idx) * A.n_checks + check;   // line buffer: this launch's checks only
                     else rec = (size_t)(idx + A.st_off) * A.nc + check;
                     const int4* src = (arg == K_LINE ? A.lines : (const int4*)A.state) + rec * 4;
                     int4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
@@ -781,6 +781,10 @@ struct CoopDev {
     CoopPipe pipe[MAX_PIPES];
     int n_pipes;
     size_t chunk;            // checks per pipeline pass (bounds the line-stream workspace: 26 KB per pair)
+    size_t super;            // checks per two-phase final exponentiation (one batched inversion for all of them)
+    bool c_single;           // phase C as one launch per super-chunk (default) or per chunk on the pipelines
+    int4* big_state;         // per-check state of a whole super-chunk (7.9 KB per check)
+    size_t big_state_bytes;
     hipEvent_t ready;
 };
 
@@ -809,6 +813,11 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     ev = getenv("ZKP_COOP_CHUNK");
     d->chunk = ev ? (size_t)atol(ev) : ((size_t)1 << 16);   // measured best: 2 pipes x 2^16 checks
     if (d->chunk < 320) d->chunk = 320;
+    ev = getenv("ZKP_COOP_SUPER");
+    d->super = ev ? (size_t)atol(ev) : ((size_t)1 << 20);
+    if (d->super < d->chunk) d->super = d->chunk;
+    ev = getenv("ZKP_COOP_C_SINGLE");
+    d->c_single = ev ? atoi(ev) != 0 : true;
     for (int i = 0; i < d->n_pipes; i++) {
         if ((e = hipStreamCreateWithFlags(&d->pipe[i].stream, hipStreamNonBlocking)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&d->pipe[i].done, hipEventDisableTiming)) != hipSuccess) return e;
@@ -827,6 +836,7 @@ void coop_free(CoopState* st) {
         if (d->progs[i].tbl) (void)hipFree(d->progs[i].tbl);
     }
     if (d->consts) (void)hipFree(d->consts);
+    if (d->big_state) (void)hipFree(d->big_state);
     for (int i = 0; i < MAX_PIPES; i++) {
         if (d->pipe[i].lines) (void)hipFree(d->pipe[i].lines);
         if (d->pipe[i].state) (void)hipFree(d->pipe[i].state);
@@ -908,20 +918,20 @@ static hipError_t prep(CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, con
 // (prod_i f_i is the multi-Miller value; only the shared squarings are lost).  Result: state ST_F, or the
 // canonical wire record in `wire_out` when that is not null.
 static hipError_t miller_on_pipe(CoopDev* d, CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2,
-                                 size_t base, uint32_t n, size_t k, uint64_t* wire_out) {
+                                 size_t base, uint32_t n, uint32_t nc, size_t k, uint64_t* wire_out) {
     hipError_t e;
     if (k <= MAX_GROUP) {
         if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, 0, (uint32_t)k)) != hipSuccess) return e;
-        return run_prog(d, pp, miller_prog(k, wire_out != nullptr), n, n, (uint32_t)k, nullptr, wire_out, nullptr, nullptr);
+        return run_prog(d, pp, miller_prog(k, wire_out != nullptr), n, nc, (uint32_t)k, nullptr, wire_out, nullptr, nullptr);
     }
     for (size_t j0 = 0; j0 < k; j0 += MAX_GROUP) {
         const size_t g = k - j0 < MAX_GROUP ? k - j0 : MAX_GROUP;
         if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, (uint32_t)j0, (uint32_t)g)) != hipSuccess) return e;
-        if ((e = run_prog(d, pp, miller_prog(g, false), n, n, (uint32_t)g, nullptr, nullptr, nullptr, nullptr, j0 ? ZKP_COOP_ST_G : 0)) != hipSuccess)
+        if ((e = run_prog(d, pp, miller_prog(g, false), n, nc, (uint32_t)g, nullptr, nullptr, nullptr, nullptr, j0 ? ZKP_COOP_ST_G : 0)) != hipSuccess)
             return e;
         if (j0) {
             const bool last = j0 + g == k;
-            if ((e = run_prog(d, pp, (last && wire_out) ? ZKP_PROG_F12MUL_WIRE : ZKP_PROG_F12MUL_STATE, n, n, 1, nullptr, last ? wire_out : nullptr,
+            if ((e = run_prog(d, pp, (last && wire_out) ? ZKP_PROG_F12MUL_WIRE : ZKP_PROG_F12MUL_STATE, n, nc, 1, nullptr, last ? wire_out : nullptr,
                               nullptr, nullptr)) != hipSuccess)
                 return e;
         }
@@ -933,7 +943,7 @@ static hipError_t miller_on_pipe(CoopDev* d, CoopPipe* pp, const uint64_t* g1, c
 // stream `s` is forked into the pipeline streams (they wait for everything already queued on `s`) and
 // joined again at the end, so from the caller's point of view the call is ordered on `s`.
 template <class Body>
-static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lines, hipStream_t s, Body body) {
+static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lines, bool need_state, hipStream_t s, Body body) {
     if (!n_total) return hipSuccess;
     hipError_t e;
     size_t chunk = d->chunk;
@@ -944,7 +954,7 @@ static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lin
     for (int i = 0; i < pipes; i++) {
         const size_t kg = k < MAX_GROUP ? k : MAX_GROUP;
         if (need_lines && (e = ensure_buf(&d->pipe[i].lines, &d->pipe[i].lines_bytes, (size_t)NLINES * kg * 6 * cmax * 64)) != hipSuccess) return e;
-        if ((e = ensure_buf(&d->pipe[i].state, &d->pipe[i].state_bytes, (size_t)ST_SIZE * cmax * 64)) != hipSuccess) return e;
+        if (need_state && (e = ensure_buf(&d->pipe[i].state, &d->pipe[i].state_bytes, (size_t)ST_SIZE * cmax * 64)) != hipSuccess) return e;
     }
     if ((e = hipEventRecord(d->ready, s)) != hipSuccess) return e;
     for (int i = 0; i < pipes; i++)
@@ -965,24 +975,52 @@ hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, co
                        uint64_t* out, hipStream_t s) {
     CoopDev* d = (CoopDev*)st->d_prog;
     if (!coop_supports_k(k)) return hipErrorNotSupported;
-    return for_chunks(d, n_checks, k, true, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
-        return miller_on_pipe(d, pp, g1, g2, i1, i2, base, n, k, out + 72 * base);
+    return for_chunks(d, n_checks, k, true, true, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
+        return miller_on_pipe(d, pp, g1, g2, i1, i2, base, n, n, k, out + 72 * base);
     });
 }
 
-static hipError_t fexp_tail(CoopDev* d, CoopPipe* pp, uint32_t n, uint64_t* out, uint8_t* ok, int* all_ok) {
-    hipLaunchKernelGGL(k_batch_inv, dim3((n + 63) / 64), dim3(64), 0, pp->stream, pp->state, n, n);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return run_prog(d, pp, ZKP_PROG_FEXP_C, n, n, 1, nullptr, out, ok, all_ok);
+// Final exponentiation in two phases over a super-chunk of checks that share ONE state buffer: phase A per chunk on
+// the pipelines (whatever produces ST_F, then fexp_a down to the single Fp inversion), ONE batched inversion over all
+// checks of the super-chunk (k_batch_inv is latency bound: per 2^16-check chunk it would leave the GPU idle for ~1.5 ms),
+// phase C (fexp_c) per chunk.
+template <class PhaseA>
+static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_lines, hipStream_t s, uint64_t* out, uint8_t* ok, int* all_ok,
+                            PhaseA phase_a) {
+    hipError_t e;
+    for (size_t sb = 0; sb < n_total; sb += d->super) {
+        const size_t ns = n_total - sb < d->super ? n_total - sb : d->super;
+        if ((e = ensure_buf(&d->big_state, &d->big_state_bytes, (size_t)ST_SIZE * ns * 64)) != hipSuccess) return e;
+        e = for_chunks(d, ns, k, need_lines, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
+            CoopPipe v = *pp;
+            v.state = d->big_state + 4 * base;
+            return phase_a(&v, sb + base, n, (uint32_t)ns);
+        });
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_batch_inv, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, s, d->big_state, (uint32_t)ns, (uint32_t)ns);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (d->c_single) {   // phase C needs no line buffer: one launch over the whole super-chunk, no per-chunk tails
+            CoopPipe v = d->pipe[0];
+            v.state = d->big_state;
+            v.stream = s;
+            e = run_prog(d, &v, ZKP_PROG_FEXP_C, (uint32_t)ns, (uint32_t)ns, 1, nullptr, out ? out + 72 * sb : nullptr, ok ? ok + sb : nullptr, all_ok);
+        } else {
+            e = for_chunks(d, ns, 1, false, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
+                CoopPipe v = *pp;
+                v.state = d->big_state + 4 * base;
+                return run_prog(d, &v, ZKP_PROG_FEXP_C, n, (uint32_t)ns, 1, nullptr, out ? out + 72 * (sb + base) : nullptr,
+                                ok ? ok + sb + base : nullptr, all_ok);
+            });
+        }
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t coop_final_exp(CoopState* st, const uint64_t* f, size_t n_total, uint64_t* out, uint8_t* ok, int* all_ok, hipStream_t s) {
     CoopDev* d = (CoopDev*)st->d_prog;
-    return for_chunks(d, n_total, 1, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
-        hipError_t e = run_prog(d, pp, ZKP_PROG_FEXP_A_WIRE, n, n, 1, f + 72 * base, nullptr, nullptr, nullptr);
-        if (e != hipSuccess) return e;
-        return fexp_tail(d, pp, n, out ? out + 72 * base : nullptr, ok ? ok + base : nullptr, all_ok);
+    return two_phase(d, n_total, 1, false, s, out, ok, all_ok, [&](CoopPipe* pp, size_t base, uint32_t n, uint32_t nc) -> hipError_t {
+        return run_prog(d, pp, ZKP_PROG_FEXP_A_WIRE, n, nc, 1, f + 72 * base, nullptr, nullptr, nullptr);
     });
 }
 
@@ -999,11 +1037,10 @@ hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, c
                         uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s) {
     CoopDev* d = (CoopDev*)st->d_prog;
     if (!coop_supports_k(k)) return hipErrorNotSupported;
-    return for_chunks(d, n_checks, k, true, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
-        hipError_t e = miller_on_pipe(d, pp, g1, g2, i1, i2, base, n, k, nullptr);
+    return two_phase(d, n_checks, k, true, s, out_gt, ok, all_ok, [&](CoopPipe* pp, size_t base, uint32_t n, uint32_t nc) -> hipError_t {
+        hipError_t e = miller_on_pipe(d, pp, g1, g2, i1, i2, base, n, nc, k, nullptr);
         if (e != hipSuccess) return e;
-        if ((e = run_prog(d, pp, ZKP_PROG_FEXP_A_STATE, n, n, 1, nullptr, nullptr, nullptr, nullptr)) != hipSuccess) return e;
-        return fexp_tail(d, pp, n, out_gt ? out_gt + 72 * base : nullptr, ok ? ok + base : nullptr, all_ok);
+        return run_prog(d, pp, ZKP_PROG_FEXP_A_STATE, n, nc, 1, nullptr, nullptr, nullptr, nullptr);
     });
 }
 
