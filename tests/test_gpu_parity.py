@@ -366,6 +366,31 @@ def test_fp12_product_and_one_product_check(keng):
     assert res is True
 
 
+def test_simultaneous_inversion_paths(monkeypatch):
+    """the final exponentiation's batched Fp inversion with several checks per lane (Montgomery's trick), ragged
+    tail included; a zero (non-invertible) input must not disturb the checks that share its lane."""
+    from zkvm_pairings_amd import PairingEngine, synthetic
+    monkeypatch.setenv("ZKP_COOP_INV_LANES", "16")      # 1003 checks -> 8 per lane on 126 lanes
+    e = PairingEngine(0, kernel="coop")
+    try:
+        n = 1003
+        g1, g2, _, _ = synthetic.random_pairs(e, n, seed=4711)
+        ml = e.multi_miller_loop(g1, g2, 1)
+        want = o.final_exponentiation_batch(ml[:96])
+        assert np.array_equal(e.final_exponentiation(ml)[:96], want)
+        assert np.array_equal(e.pairing(g1, g2)[:96], want)
+        bad = ml.copy()
+        bad[[0, 5, 500, 1002]] = 0
+        got = e.final_exponentiation(bad)
+        keep = np.ones(n, dtype=bool)
+        keep[[0, 5, 500, 1002]] = False
+        assert np.array_equal(got[keep][:90], want[keep[:96]][:90])
+        ref = e.final_exponentiation(ml)
+        assert np.array_equal(got[keep], ref[keep])
+    finally:
+        e.close()
+
+
 def test_config2_full_batch_bit_exact(eng):
     """BASELINE.json config 2: 2^16 random (G1,G2) pairs on one GPU, EVERY Gt compared with the CPU oracle."""
     import hashlib

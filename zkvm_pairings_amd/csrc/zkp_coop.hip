@@ -10,7 +10,7 @@
 //                    MULACC  sum of <=12 products into 64-bit columns, ONE Montgomery reduction
 //                    LIN     limb-wise linear combination (no carries), weak normalisation
 //                    GLOAD/GSTORE  line stream / per-check state / wire format
-//   k_batch_inv    one lane per check: the single Fp inversion of the final exponentiation.
+//   k_batch_inv    the single Fp inversion of the final exponentiation, up to 8 checks per lane (Montgomery's trick).
 // Programs: miller{k}_{state|wire}, fexp_a_{state|wire}, fexp_c (zkp_coop_prog.inc).
 //
 // Reference anchors: Fp12::mul_by_014 src/fp12.rs:99-111, Fp12::square :173-184, Fp12::invert
@@ -741,14 +741,46 @@ __global__ void __launch_bounds__(64, 2) k_g2_mul28(const uint64_t* base, size_t
     }
 }
 
-// one lane per check: state[ST_NINV] = state[ST_N]^-1 (Fermat, a^(p-2); reference src/fp.rs:307-319)
-__global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks, uint32_t nc) {
+// state[ST_NINV] = state[ST_N]^-1 for every check.  One lane inverts B checks (i, i + L, i + 2L, ...; L lanes) with
+// Montgomery's simultaneous inversion: exclusive prefix products parked in the ST_NINV records, ONE Fermat inversion
+// (a^(p-2); reference src/fp.rs:307-319) of the total, then two multiplications per check on the way back.
+// A zero element (a non-invertible final_exponentiation input) is replaced by one in the chain and gets 0, as Fermat gives.
+__global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks, uint32_t nc, uint32_t B) {
+    const uint32_t L = (n_checks + B - 1) / B;
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_checks) return;
-    Fp28 a;
-    rec_load(a, state + ((size_t)ZKP_COOP_ST_N * nc + i) * 4);
-    Fp28 res = f_inv(a);
-    rec_store(state + ((size_t)ZKP_COOP_ST_NINV * nc + i) * 4, res);
+    if (i >= L) return;
+    int4* N = state + (size_t)ZKP_COOP_ST_N * nc * 4;
+    int4* I = state + (size_t)ZKP_COOP_ST_NINV * nc * 4;
+    Fp28 acc = f_const(K28_ONE);
+    uint32_t cnt = 0;
+#pragma unroll 1
+    for (uint32_t idx = i; idx < n_checks && cnt < B; idx += L, cnt++) {
+        Fp28 e;
+        rec_load(e, N + (size_t)idx * 4);
+        if (B > 1) {
+            rec_store(I + (size_t)idx * 4, acc);
+            if (f_is_zero(e)) e = f_const(K28_ONE);
+            fp28_mul(acc, acc, e);
+        } else {
+            acc = e;
+        }
+    }
+    Fp28 inv = f_inv(acc);
+    if (B == 1) { rec_store(I + (size_t)i * 4, inv); return; }
+#pragma unroll 1
+    for (uint32_t j = cnt; j-- > 0;) {
+        const size_t idx = (size_t)i + (size_t)j * L;
+        Fp28 e, pre, r;
+        rec_load(e, N + idx * 4);
+        rec_load(pre, I + idx * 4);
+        if (f_is_zero(e)) {
+            f_zero(r);
+        } else {
+            fp28_mul(r, inv, pre);
+            fp28_mul(inv, inv, e);
+        }
+        rec_store(I + idx * 4, r);
+    }
 }
 
 // fp28 multiply on wire operands (test hook for the 28-bit core)
@@ -783,6 +815,8 @@ struct CoopDev {
     size_t chunk;            // checks per pipeline pass (bounds the line-stream workspace: 26 KB per pair)
     size_t super;            // checks per two-phase final exponentiation (one batched inversion for all of them)
     bool c_single;           // phase C as one launch per super-chunk (default) or per chunk on the pipelines
+    uint32_t inv_batch;      // most checks one lane inverts together (Montgomery's trick)
+    size_t inv_lanes;        // ... and the number of lanes the inversion kernel keeps busy before it batches
     int4* big_state;         // per-check state of a whole super-chunk (7.9 KB per check)
     size_t big_state_bytes;
     hipEvent_t ready;
@@ -818,6 +852,12 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     if (d->super < d->chunk) d->super = d->chunk;
     ev = getenv("ZKP_COOP_C_SINGLE");
     d->c_single = ev ? atoi(ev) != 0 : true;
+    ev = getenv("ZKP_COOP_INV_BATCH");
+    d->inv_batch = ev ? (uint32_t)atoi(ev) : 8;
+    if (d->inv_batch < 1) d->inv_batch = 1;
+    ev = getenv("ZKP_COOP_INV_LANES");
+    d->inv_lanes = ev ? (size_t)atol(ev) : ((size_t)1 << 17);
+    if (d->inv_lanes < 1) d->inv_lanes = 1;
     for (int i = 0; i < d->n_pipes; i++) {
         if ((e = hipStreamCreateWithFlags(&d->pipe[i].stream, hipStreamNonBlocking)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&d->pipe[i].done, hipEventDisableTiming)) != hipSuccess) return e;
@@ -997,7 +1037,11 @@ static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_line
             return phase_a(&v, sb + base, n, (uint32_t)ns);
         });
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_batch_inv, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, s, d->big_state, (uint32_t)ns, (uint32_t)ns);
+        // checks per lane: keep >= 2^17 lanes (two waves per SIMD) so that the chain latency stays covered
+        uint32_t B = (uint32_t)(ns / d->inv_lanes);
+        B = B < 1 ? 1 : (B > d->inv_batch ? d->inv_batch : B);
+        const size_t lanes = (ns + B - 1) / B;
+        hipLaunchKernelGGL(k_batch_inv, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, d->big_state, (uint32_t)ns, (uint32_t)ns, B);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if (d->c_single) {   // phase C needs no line buffer: one launch over the whole super-chunk, no per-chunk tails
             CoopPipe v = d->pipe[0];
