@@ -17,7 +17,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GLOBAL_PAIRS = 1 << 20
-PMC_PASS_PAIRS = 1 << 17   # size of the pass profiles/r01/pmc/traffic.json was measured on
 # algorithmic work per pairing with the reference-shaped tower =
 # 21,869 Fp-mul-equivalents x 300 32x32->64 multiply-adds (CIOS, 12 limbs)
 MACS_PER_PAIRING = 21869 * 300
@@ -112,8 +111,9 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01", "pmc", "traffic.json")
         if os.path.exists(tpath) and args.kernel in ("auto", "coop"):
-            with open(tpath) as tf:   # rocprofv3 PMC passes over a 2^17-pair pass, gfx950-corrected (see file); linear in n
-                traffic = json.load(tf)["hbm_bytes_per_step"] * n / PMC_PASS_PAIRS
+            with open(tpath) as tf:   # rocprofv3 PMC passes over one 2^20-pair pass, gfx950-corrected (tools/pmc_traffic.py); linear in n
+                tj = json.load(tf)
+                traffic = tj["hbm_bytes_per_step"] * n / tj["pairs_per_step"]
         # bit-exact parity of a seeded sample vs the CPU oracle + timing of the oracle on the host cores
         cpu = None
         parity = None
@@ -144,7 +144,7 @@ def main():
                          "achieved": achieved / 1e12, "peak": PEAK_MACS / 1e12, "unit": "T u32-MAC/s",
                          "frac": achieved / PEAK_MACS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_macs_per_pairing": MACS_PER_PAIRING,
-                         "launch": "one pass over the resident batch = k_prep_lines + k_coop(miller) + k_coop(fexp_a) + k_batch_inv + k_coop(fexp_c) per 2^16-check chunk, chunks on two overlapped HIP streams; kernel_ms is that pass timed with HIP events on the launching stream (profiles/r01/v7_pass_timeline.txt)"},
+                         "launch": "one pass over the resident batch = phase A per 2^16-check chunk on two overlapped HIP streams (k_prep_lines, k_coop miller, k_coop fexp_a), ONE k_batch_inv and ONE k_coop fexp_c launch over the whole shard; kernel_ms is that pass timed with HIP events on the launching stream (profiles/r01/v13_pass_timeline.txt)"},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

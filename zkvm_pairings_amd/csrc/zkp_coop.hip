@@ -395,32 +395,33 @@ __device__ __forceinline__ Fp28 c_neg(const Fp28& a) {
 
 struct G2C { Fp28 x, y, z; };   // this lane's coefficient of the three Jacobian coordinates
 
-// ePrint 2010/354 Alg. 26; returns this lane's coefficient of the line (c0, c1, c2) and advances r
-__device__ __forceinline__ void dbl_step(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, int c) {
-    Fp28 tmp0 = c_sqr(r.x, c);
+// ePrint 2010/354 Alg. 26; hands this lane's coefficient of the line (c0, c1, c2) to the three sinks and advances r.
+// The operations are ordered so that few values are live at any call: a by-value call keeps the caller's values in
+// the ~108 callee-saved VGPRs only, everything beyond that is spilled around EVERY call (that was 100 GB of scratch
+// traffic per 2^20 pairs); the line coefficients leave through the sinks as soon as they exist.
+template <class S0, class S1, class S2>
+__device__ __forceinline__ void dbl_step(G2C& r, int c, S0&& sink_l0, S1&& sink_l1, S2&& sink_l2) {
+    Fp28 zsq = c_sqr(r.z, c);
+    Fp28 nz = c_sqr(c_add(r.z, r.y), c);
     Fp28 tmp1 = c_sqr(r.y, c);
-    Fp28 tmp2 = c_sqr(tmp1, c);
-    Fp28 tmp3 = c_sqr(c_add(tmp1, r.x), c);
-    tmp3 = c_sub(c_sub(tmp3, tmp0), tmp2);
-    tmp3 = c_dbl(tmp3);
+    nz = c_sub(c_sub(nz, tmp1), zsq);
+    Fp28 tmp0 = c_sqr(r.x, c);
     Fp28 tmp4 = c_add(c_add(tmp0, tmp0), tmp0);
     Fp28 tmp6 = c_add(r.x, tmp4);
+    Fp28 tmp3 = c_sqr(c_add(tmp1, r.x), c);
+    Fp28 tmp2 = c_sqr(tmp1, c);
+    tmp3 = c_dbl(c_sub(c_sub(tmp3, tmp0), tmp2));
+    sink_l1(c_neg(c_dbl(c_mul(tmp4, zsq, c))));
+    sink_l0(c_dbl(c_mul(nz, zsq, c)));
     Fp28 tmp5 = c_sqr(tmp4, c);
-    Fp28 zsq = c_sqr(r.z, c);
     Fp28 nx = c_sub(c_sub(tmp5, tmp3), tmp3);
-    Fp28 nz = c_sqr(c_add(r.z, r.y), c);
-    nz = c_sub(c_sub(nz, tmp1), zsq);
-    Fp28 ny = c_mul(c_sub(tmp3, nx), tmp4, c);
-    tmp2 = c_dbl(c_dbl(c_dbl(tmp2)));
-    ny = c_sub(ny, tmp2);
-    tmp3 = c_neg(c_dbl(c_mul(tmp4, zsq, c)));
     tmp6 = c_sqr(tmp6, c);
     tmp6 = c_sub(c_sub(tmp6, tmp0), tmp5);
-    tmp6 = c_sub(tmp6, c_dbl(c_dbl(tmp1)));
-    tmp0 = c_dbl(c_mul(nz, zsq, c));
+    sink_l2(c_sub(tmp6, c_dbl(c_dbl(tmp1))));
+    Fp28 ny = c_mul(c_sub(tmp3, nx), tmp4, c);
+    ny = c_sub(ny, c_dbl(c_dbl(c_dbl(tmp2))));
     vred(nx.l); vred(ny.l); vred(nz.l);
     r.x = nx; r.y = ny; r.z = nz;
-    l0 = tmp0; l1 = tmp3; l2 = tmp6;
 }
 // ePrint 2010/354 Alg. 27
 __device__ __forceinline__ void add_step(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, const Fp28& qx, const Fp28& qy, int c) {
@@ -472,48 +473,68 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
     const size_t src = (size_t)check * k_in + j0 + j;
     const bool dead = (inf1 && inf1[src]) || (inf2 && inf2[src]);
     auto rec = [&](uint32_t step, uint32_t e) -> int4* { return lines + ((((size_t)step * k + j) * 6 + e) * nc + check) * 4; };
-    Fp28 px, py, qx, qy;
-    fp28_from_wire(px, g1 + 12 * src);
-    fp28_from_wire(py, g1 + 12 * src + 6);
-    fp28_from_wire(qx, g2 + 24 * src + 6 * c);
-    fp28_from_wire(qy, g2 + 24 * src + 12 + 6 * c);
+    // P = (px, py) and Q = (qx, qy) are needed once per step / five times per loop: parked in LDS (limb quad q of
+    // value v at [(v * 4 + q) * 64 + lane], conflict-free) instead of occupying 56 VGPRs across every call
+    __shared__ int4 park[4 * 4 * 64];
+    const int lane = threadIdx.x;
+    enum { PX = 0, PY = 1, QX = 2, QY = 3 };
+    auto park_st = [&](int v, const Fp28& x) {
+        park[(v * 4 + 0) * 64 + lane] = make_int4(x.l[0], x.l[1], x.l[2], x.l[3]);
+        park[(v * 4 + 1) * 64 + lane] = make_int4(x.l[4], x.l[5], x.l[6], x.l[7]);
+        park[(v * 4 + 2) * 64 + lane] = make_int4(x.l[8], x.l[9], x.l[10], x.l[11]);
+        park[(v * 4 + 3) * 64 + lane] = make_int4(x.l[12], x.l[13], 0, 0);
+    };
+    auto park_ld = [&](int v) -> Fp28 {
+        asm volatile("" ::: "memory");   // keep the load at its use (no hoisting out of the step loop)
+        const int4 v0 = park[(v * 4 + 0) * 64 + lane], v1 = park[(v * 4 + 1) * 64 + lane], v2 = park[(v * 4 + 2) * 64 + lane],
+                   v3 = park[(v * 4 + 3) * 64 + lane];
+        Fp28 x;
+        x.l[0] = v0.x; x.l[1] = v0.y; x.l[2] = v0.z; x.l[3] = v0.w; x.l[4] = v1.x; x.l[5] = v1.y; x.l[6] = v1.z; x.l[7] = v1.w;
+        x.l[8] = v2.x; x.l[9] = v2.y; x.l[10] = v2.z; x.l[11] = v2.w; x.l[12] = v3.x; x.l[13] = v3.y;
+        return x;
+    };
     G2C r;
-    r.x = qx;
-    r.y = qy;
+    {
+        Fp28 t;
+        fp28_from_wire(t, g1 + 12 * src);
+        park_st(PX, t);
+        fp28_from_wire(t, g1 + 12 * src + 6);
+        park_st(PY, t);
+        fp28_from_wire(r.x, g2 + 24 * src + 6 * c);
+        park_st(QX, r.x);
+        fp28_from_wire(r.y, g2 + 24 * src + 12 + 6 * c);
+        park_st(QY, r.y);
+    }
     if (c == 0) f_set(r.z, K28_ONE); else f_zero(r.z);
     uint32_t step = 0;
-    Fp28 one_or_zero;
-    if (c == 0) f_set(one_or_zero, K28_ONE); else f_zero(one_or_zero);
-    auto emit = [&](Fp28& l0, Fp28& l1, Fp28& l2) {
-        // stream order (c2, c1 * xP, c0 * yP) = the (c0, c1, c4) operands of mul_by_014; a pair with an
-        // infinity streams the neutral line (1, 0, 0)
-        vred(l2.l);
-        Fp28 t1 = f_mul_v(l1, px);
-        Fp28 t0 = f_mul_v(l0, py);
-        if (live_lane) {
-            Fp28 z;
-            f_zero(z);
-            rec_store(rec(step, 0 + c), dead ? one_or_zero : l2);
-            rec_store(rec(step, 2 + c), dead ? z : t1);
-            rec_store(rec(step, 4 + c), dead ? z : t0);
-        }
-        step++;
+    // stream order (c2, c1 * xP, c0 * yP) = the (c0, c1, c4) operands of mul_by_014; a pair with an infinity streams
+    // the neutral line (1, 0, 0)
+    auto put = [&](uint32_t e, const Fp28& v) {
+        if (!live_lane) return;
+        Fp28 o;
+#pragma unroll
+        for (int i = 0; i < NL; i++) o.l[i] = dead ? ((e == 0 && c == 0) ? K28_ONE[i] : 0) : v.l[i];
+        rec_store(rec(step, e + c), o);
     };
-    Fp28 l0, l1, l2;
-    const uint64_t xs = 0xd201000000010000ULL >> 1;
-    bool found = false;
-    for (int b = 63; b >= 0; b--) {
-        const bool bit = (xs >> b) & 1;
-        if (!found) { found = bit; continue; }
-        dbl_step(l0, l1, l2, r, c);
-        emit(l0, l1, l2);
-        if (bit) {
-            add_step(l0, l1, l2, r, qx, qy, c);
-            emit(l0, l1, l2);
+    auto sink_l0 = [&](const Fp28& l0) { put(4, f_mul_v(l0, park_ld(PY))); };
+    auto sink_l1 = [&](const Fp28& l1) { put(2, f_mul_v(l1, park_ld(PX))); };
+    auto sink_l2 = [&](Fp28 l2) { vred(l2.l); put(0, l2); };
+    // bits of |x| below its leading one: a doubling step each, an addition step after it where the bit is set
+    // (the lowest bit is clear: the loop ends with the final doubling) -> 63 + 5 = 68 line records
+    const uint64_t xs = 0xd201000000010000ULL;
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+        dbl_step(r, c, sink_l0, sink_l1, sink_l2);
+        step++;
+        if ((xs >> b) & 1) {
+            Fp28 l0, l1, l2;
+            add_step(l0, l1, l2, r, park_ld(QX), park_ld(QY), c);
+            sink_l2(l2);
+            sink_l1(l1);
+            sink_l0(l0);
+            step++;
         }
     }
-    dbl_step(l0, l1, l2, r, c);
-    emit(l0, l1, l2);
 }
 
 // =============================================================================== validity checks on the 28-bit core
