@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkp_pairings.so")
+# ZKP_LIB_PATH: A/B timing of two builds of the same library on one GPU box (development only)
+LIB_PATH = os.environ.get("ZKP_LIB_PATH") or os.path.join(_HERE, "libzkp_pairings.so")
 
 c_u64p = ctypes.POINTER(ctypes.c_uint64)
 c_u8p = ctypes.POINTER(ctypes.c_uint8)

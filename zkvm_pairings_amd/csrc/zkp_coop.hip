@@ -170,6 +170,11 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 } else if (no_a2) {
 #pragma unroll
                     for (int i = 0; i < NL; i++) a[i] = (xa[i] ^ mn) - mn;
+                } else if (no_neg) {
+                    int32_t x2[NL];
+                    ld(x2, (w >> 7) & 127);
+#pragma unroll
+                    for (int i = 0; i < NL; i++) a[i] = xa[i] + ((x2[i] ^ ma) - ma);
                 } else {
                     int32_t x2[NL];
                     ld(x2, (w >> 7) & 127);
