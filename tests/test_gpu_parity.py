@@ -366,6 +366,38 @@ def test_fp12_product_and_one_product_check(keng):
     assert res is True
 
 
+def test_host_pointer_entry_points_in_slices(monkeypatch):
+    """host arrays larger than ZKP_HOST_SLICE pairs go through the sliced pipeline (upload of the next slice and
+    download of the previous one overlap the current slice's kernels): same results as the one-shot path, ragged
+    last slice, infinity flags, k = 1 and k = 3, AND flag accumulated over slices."""
+    from zkvm_pairings_amd import PairingEngine, synthetic
+    monkeypatch.setenv("ZKP_HOST_SLICE", "96")       # pairing: > 96 pairs sliced; checks: > 768 pairs sliced
+    e = PairingEngine(0)
+    try:
+        n = 1003
+        g1, g2, _, _ = synthetic.random_pairs(e, n, seed=2024)
+        inf1 = np.zeros(n, dtype=np.uint8)
+        inf2 = np.zeros(n, dtype=np.uint8)
+        inf1[[0, 95, 96, 500]] = 1
+        inf2[[97, 1002]] = 1
+        got = e.pairing(g1, g2, inf1, inf2)
+        want = o.pairing_batch(g1, g2, inf1, inf2, NTHREADS)
+        assert np.array_equal(got, want)
+        ok, allok = e.pairing_check(g1, g2, 1, inf1, inf2)
+        exp = (inf1 | inf2).astype(np.uint8)
+        assert np.array_equal(ok, exp) and not allok
+        ok, allok = e.pairing_check(g1, g2, 1, np.ones(n, dtype=np.uint8), None)
+        assert ok.all() and allok
+        G1, G2, expect = _groth_like_checks(e, 301, 777, 5)
+        ok, allok = e.pairing_check(G1, G2, 3)
+        assert np.array_equal(ok, expect) and not allok
+        G1, G2, expect = _groth_like_checks(e, 301, 778, 0)
+        ok, allok = e.pairing_check(G1, G2, 3)
+        assert ok.all() and allok
+    finally:
+        e.close()
+
+
 def test_simultaneous_inversion_paths(monkeypatch):
     """the final exponentiation's batched Fp inversion with several checks per lane (Montgomery's trick), ragged
     tail included; a zero (non-invertible) input must not disturb the checks that share its lane."""

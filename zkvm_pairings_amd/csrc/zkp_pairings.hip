@@ -305,6 +305,15 @@ struct zkp_ctx {
     int* d_flag = nullptr;
     uint64_t* prod = nullptr;   // Fp12 records of the product tree (zkp_fp12_product / zkp_miller_product)
     size_t prod_cap = 0;
+    // host-pointer pairing entry points on large batches: slices of host_slice pairs, two workspace slots, copies of
+    // the next / previous slice on their own streams while the current slice computes
+    struct HostSlot {
+        void* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // g1 g2 inf1 inf2 gt ok
+        size_t cap[6] = {0, 0, 0, 0, 0, 0};
+        hipEvent_t in = nullptr, done = nullptr, out = nullptr;
+    } hs[2];
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    size_t host_slice = (size_t)1 << 19;
     hipDeviceProp_t prop;
     zkp::CoopState coop;
 };
@@ -368,8 +377,8 @@ int final_exp_dev(zkp_ctx* c, const uint64_t* f, size_t n, uint64_t* out, hipStr
     return ZKP_OK;
 }
 int pairing_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
-                uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s) {
-    if (all_ok) {
+                uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s, bool reset_flag = true) {
+    if (all_ok && reset_flag) {
         hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, all_ok, 1);
         HIPCHK(c, hipGetLastError());
     }
@@ -466,6 +475,84 @@ int validate_dev(zkp_ctx* c, const uint64_t* d, size_t n_fp) {
 
 struct Staged { const uint64_t *g1, *g2; const uint8_t *i1, *i2; };
 
+int ensure_slot(zkp_ctx* c, zkp_ctx::HostSlot* h, int which, size_t bytes) {
+    if (bytes <= h->cap[which]) return ZKP_OK;
+    if (h->buf[which]) { HIPCHK(c, hipFree(h->buf[which])); h->buf[which] = nullptr; h->cap[which] = 0; }
+    HIPCHK(c, hipMalloc(&h->buf[which], bytes));
+    h->cap[which] = bytes;
+    return ZKP_OK;
+}
+
+// pairing()/pairing check of n_checks x k pairs from HOST arrays in slices: while slice i computes on the context's
+// stream, the host thread uploads slice i+1 (copy-in stream) and downloads the results of slice i-1 (copy-out stream).
+// out_gt / ok / all_ok are host pointers, each optional.
+int host_sliced(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks, size_t k,
+                uint64_t* out_gt, uint8_t* ok, int* all_ok) {
+    const size_t sc = c->host_slice / k ? c->host_slice / k : 1;   // checks per slice
+    const size_t nsl = (n_checks + sc - 1) / sc;
+    int rc;
+    if (!c->s_in) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->hs[i].in, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->hs[i].done, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->hs[i].out, hipEventDisableTiming));
+        }
+    }
+    for (int i = 0; i < 2; i++) {
+        zkp_ctx::HostSlot* h = &c->hs[i];
+        if ((rc = ensure_slot(c, h, 0, sc * k * 96)) || (rc = ensure_slot(c, h, 1, sc * k * 192))) return rc;
+        if (inf1 && (rc = ensure_slot(c, h, 2, sc * k))) return rc;
+        if (inf2 && (rc = ensure_slot(c, h, 3, sc * k))) return rc;
+        if (out_gt && (rc = ensure_slot(c, h, 4, sc * 576))) return rc;
+        if ((rc = ensure_slot(c, h, 5, sc))) return rc;
+    }
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, c->d_flag + 1, 1);
+    HIPCHK(c, hipGetLastError());
+    auto upload = [&](size_t i) -> int {
+        zkp_ctx::HostSlot* h = &c->hs[i & 1];
+        const size_t c0 = i * sc, ns = n_checks - c0 < sc ? n_checks - c0 : sc, p0 = c0 * k, np = ns * k;
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_in, h->done, 0));   // slice i-2 has finished reading these buffers
+        HIPCHK(c, hipMemcpyAsync(h->buf[0], g1 + 12 * p0, np * 96, hipMemcpyHostToDevice, c->s_in));
+        HIPCHK(c, hipMemcpyAsync(h->buf[1], g2 + 24 * p0, np * 192, hipMemcpyHostToDevice, c->s_in));
+        if (inf1) HIPCHK(c, hipMemcpyAsync(h->buf[2], inf1 + p0, np, hipMemcpyHostToDevice, c->s_in));
+        if (inf2) HIPCHK(c, hipMemcpyAsync(h->buf[3], inf2 + p0, np, hipMemcpyHostToDevice, c->s_in));
+        HIPCHK(c, hipEventRecord(h->in, c->s_in));
+        return ZKP_OK;
+    };
+    auto download = [&](size_t i) -> int {
+        zkp_ctx::HostSlot* h = &c->hs[i & 1];
+        const size_t c0 = i * sc, ns = n_checks - c0 < sc ? n_checks - c0 : sc;
+        HIPCHK(c, hipStreamWaitEvent(c->s_out, h->done, 0));
+        if (out_gt) HIPCHK(c, hipMemcpyAsync(out_gt + 72 * c0, h->buf[4], ns * 576, hipMemcpyDeviceToHost, c->s_out));
+        if (ok) HIPCHK(c, hipMemcpyAsync(ok + c0, h->buf[5], ns, hipMemcpyDeviceToHost, c->s_out));
+        HIPCHK(c, hipEventRecord(h->out, c->s_out));
+        return ZKP_OK;
+    };
+    if ((rc = upload(0))) return rc;
+    for (size_t i = 0; i < nsl; i++) {
+        zkp_ctx::HostSlot* h = &c->hs[i & 1];
+        const size_t c0 = i * sc, ns = n_checks - c0 < sc ? n_checks - c0 : sc;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, h->in, 0));
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, h->out, 0));   // results of slice i-2 have left the output buffers
+        if ((rc = pairing_dev(c, (const uint64_t*)h->buf[0], (const uint64_t*)h->buf[1], inf1 ? (const uint8_t*)h->buf[2] : nullptr,
+                              inf2 ? (const uint8_t*)h->buf[3] : nullptr, ns, k, out_gt ? (uint64_t*)h->buf[4] : nullptr, (uint8_t*)h->buf[5],
+                              c->d_flag + 1, c->stream, false)))
+            return rc;
+        HIPCHK(c, hipEventRecord(h->done, c->stream));
+        if (i + 1 < nsl && (rc = upload(i + 1))) return rc;
+        if (i >= 1 && (rc = download(i - 1))) return rc;
+    }
+    if ((rc = download(nsl - 1))) return rc;
+    int flag = 1;
+    HIPCHK(c, hipMemcpyAsync(&flag, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->s_out));
+    if (all_ok) *all_ok = flag;
+    return ZKP_OK;
+}
+
 // copy a (g1,g2,inf1,inf2) pair batch to workspace slots 0..3
 int stage_pairs(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t np, Staged* st) {
     int rc;
@@ -528,6 +615,10 @@ int zkp_init(int device, zkp_ctx** out_ctx) {
         delete c;
         return ZKP_ERR_HIP;
     }
+    if (const char* hsl = getenv("ZKP_HOST_SLICE")) {
+        c->host_slice = (size_t)atol(hsl);
+        if (c->host_slice < 64) c->host_slice = 64;
+    }
     const char* env = getenv("ZKP_KERNEL");
     if (env) {
         if (!strcmp(env, "thread")) c->kernel = ZKP_KERNEL_THREAD;
@@ -545,6 +636,15 @@ void zkp_free(zkp_ctx* c) {
         if (c->buf[i]) (void)hipFree(c->buf[i]);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->prod) (void)hipFree(c->prod);
+    for (int i = 0; i < 2; i++) {
+        for (int j = 0; j < 6; j++)
+            if (c->hs[i].buf[j]) (void)hipFree(c->hs[i].buf[j]);
+        if (c->hs[i].in) (void)hipEventDestroy(c->hs[i].in);
+        if (c->hs[i].done) (void)hipEventDestroy(c->hs[i].done);
+        if (c->hs[i].out) (void)hipEventDestroy(c->hs[i].out);
+    }
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -683,6 +783,7 @@ int zkp_pairing_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const 
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
+    if (n > c->host_slice && !c->validate) return host_sliced(c, g1, g2, inf1, inf2, n, 1, out_gt, nullptr, nullptr);
     Staged st;
     if ((rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st)) || (rc = ensure(c, 4, n * 576))) return rc;
     if ((rc = pairing_dev(c, st.g1, st.g2, st.i1, st.i2, n, 1, (uint64_t*)c->buf[4], nullptr, nullptr, c->stream))) return rc;
@@ -770,6 +871,8 @@ int zkp_pairing_check_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, 
     if (!n_checks) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
+    // flags-only results need no large download: one shot is faster (measured) until the upload workspace gets large
+    if (k && n_checks * k > 8 * c->host_slice && !c->validate) return host_sliced(c, g1, g2, inf1, inf2, n_checks, k, nullptr, ok, all_ok);
     Staged st = {nullptr, nullptr, nullptr, nullptr};
     if (k && (rc = stage_pairs(c, g1, g2, inf1, inf2, n_checks * k, &st))) return rc;
     if ((rc = ensure(c, 6, n_checks))) return rc;
