@@ -10,7 +10,7 @@
 //                    MULACC  sum of <=12 products into 64-bit columns, ONE Montgomery reduction
 //                    LIN     limb-wise linear combination (no carries), weak normalisation
 //                    GLOAD/GSTORE  line stream / per-check state / wire format
-//   k_batch_inv    the single Fp inversion of the final exponentiation, up to 8 checks per lane (Montgomery's trick).
+//   k_batch_inv    the single Fp inversion of the final exponentiation, up to 32 checks per lane (Montgomery's trick).
 // Programs: miller{k}_{state|wire}, fexp_a_{state|wire}, fexp_c (zkp_coop_prog.inc).
 //
 // Reference anchors: Fp12::mul_by_014 src/fp12.rs:99-111, Fp12::square :173-184, Fp12::invert
@@ -840,7 +840,7 @@ struct CoopDev {
     int n_pipes;
     size_t chunk;            // checks per pipeline pass (bounds the line-stream workspace: 26 KB per pair)
     size_t super;            // checks per two-phase final exponentiation (one batched inversion for all of them)
-    bool c_single;           // phase C as one launch per super-chunk (default) or per chunk on the pipelines
+    bool c_single;           // phase C as one launch per large super-chunk (default) or always per chunk on the pipelines
     uint32_t inv_batch;      // most checks one lane inverts together (Montgomery's trick)
     size_t inv_lanes;        // ... and the number of lanes the inversion kernel keeps busy before it batches
     int4* big_state;         // per-check state of a whole super-chunk (7.9 KB per check)
@@ -879,10 +879,10 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     ev = getenv("ZKP_COOP_C_SINGLE");
     d->c_single = ev ? atoi(ev) != 0 : true;
     ev = getenv("ZKP_COOP_INV_BATCH");
-    d->inv_batch = ev ? (uint32_t)atoi(ev) : 8;
+    d->inv_batch = ev ? (uint32_t)atoi(ev) : 32;
     if (d->inv_batch < 1) d->inv_batch = 1;
     ev = getenv("ZKP_COOP_INV_LANES");
-    d->inv_lanes = ev ? (size_t)atol(ev) : ((size_t)1 << 17);
+    d->inv_lanes = ev ? (size_t)atol(ev) : ((size_t)1 << 15);   // measured best: half a wavefront per SIMD runs its chain fastest
     if (d->inv_lanes < 1) d->inv_lanes = 1;
     for (int i = 0; i < d->n_pipes; i++) {
         if ((e = hipStreamCreateWithFlags(&d->pipe[i].stream, hipStreamNonBlocking)) != hipSuccess) return e;
@@ -1063,13 +1063,16 @@ static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_line
             return phase_a(&v, sb + base, n, (uint32_t)ns);
         });
         if (e != hipSuccess) return e;
-        // checks per lane: keep >= 2^17 lanes (two waves per SIMD) so that the chain latency stays covered
+        // checks per lane: the kernel is bound by the latency of one lane's chain (610 + 3 B multiplications), so it
+        // runs on few lanes (2^15 by default) and batches the rest
         uint32_t B = (uint32_t)(ns / d->inv_lanes);
         B = B < 1 ? 1 : (B > d->inv_batch ? d->inv_batch : B);
         const size_t lanes = (ns + B - 1) / B;
         hipLaunchKernelGGL(k_batch_inv, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, d->big_state, (uint32_t)ns, (uint32_t)ns, B);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if (d->c_single) {   // phase C needs no line buffer: one launch over the whole super-chunk, no per-chunk tails
+        // phase C needs no line buffer: one launch over a large super-chunk has no per-chunk tails (-1 % at 2^20
+        // checks); small ones do better per chunk on the two pipelines (-1 % at 2^17)
+        if (d->c_single && ns > 4 * d->chunk) {
             CoopPipe v = d->pipe[0];
             v.state = d->big_state;
             v.stream = s;
