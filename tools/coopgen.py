@@ -215,9 +215,12 @@ class V12:
     """an Fp12 value resident in 12 consecutive... (not necessarily) slots, with a sign per coefficient
     (conjugation and negation are free views)."""
 
-    def __init__(self, slots, signs=None):
+    def __init__(self, slots, signs=None, sd=None):
         self.slots = list(slots)
         self.signs = list(signs) if signs else [1] * 12
+        # optional companion slots kept by runs of cyclotomic squarings: sd[2j] holds x0 + x1 and sd[2j+1] holds
+        # x0 - x1 of the j-th Fp2 coefficient (x0, x1) = slots (2j, 2j+1); only valid while every sign is +
+        self.sd = list(sd) if sd else None
 
     def lin(self, i):
         return Lin.of(self.slots[i], self.signs[i])
@@ -277,14 +280,14 @@ def merge_terms(bil):
 
 
 def encode_form(f):
-    """Lin with <=2 slots and coefficients in {+-1} (or one slot with +-2) -> (s1, s2, sub, neg) or None"""
+    """Lin with <=2 slots and coefficients in {+-1} (or one slot with +-2) -> (s1, s2, sub, neg[, doubled]) or None"""
     items = sorted(f.items())
     if len(items) == 1:
         s, c = items[0]
         if c in (1, -1):
             return (s, ZERO, 0, c < 0)
         if c in (2, -2):
-            return (s, s, 0, c < 0)
+            return (s, ZERO, 0, c < 0, True)      # 2 x: the operand is doubled by a shift (A side only)
         return None
     if len(items) == 2:
         (s1, c1), (s2, c2) = items
@@ -313,9 +316,13 @@ class Builder:
         self.free = list(range(NSLOT - 1, -1, -1))
         self.peak = 0
         self.K = {}           # static worst-case |value|/p per group-local slot
+        self.L = {}           # limb bound of a slot in units of 2^27 (1 unless it holds a stored sum of two values)
 
     def kof(self, slot):
         return 1.0 if slot >= CONST_BASE else self.K.get(slot, self.K_INPUT)
+
+    def lof(self, slot):
+        return 1 if slot >= CONST_BASE else self.L.get(slot, 1)
 
     # ---- slots
     def alloc(self, n=1):
@@ -347,13 +354,17 @@ class Builder:
             kout.append(sum(abs(c) * self.kof(s) for s, c in terms))
         vred_needed = max(kout) > self.K_MAX
         assert max(kout) < 14, "LIN result too large even for the renormalisation"
+        assert all(self.lof(s) == 1 for _, terms in ent for s, _ in terms)
         for (dst, _), k in zip(ent, kout):
+            self.L[dst] = 1
             self.K[dst] = self.K_VRED if vred_needed else k
         self.steps.append({"op": OP_LIN, "nt": nt, "lanes": ent, "vred": vred_needed})
 
-    def mulacc(self, outs):
+    def mulacc(self, outs, subst=None, sd=None):
         """outs: list (<=12) of dict(dst=slot, bil=Bil or list of (Lin,Lin) merged, alpha=1, beta=0, e=ZERO).
-        Forms that do not fit the on-the-fly encoding are materialised by LIN pre-steps."""
+        Forms that do not fit the on-the-fly encoding are materialised by LIN pre-steps.
+        subst: {form key: Lin} - forms that already exist as stored values (companion sums/differences);
+        sd: per lane a companion slot (or None): lane 2j also stores r_2j + r_2j+1, lane 2j+1 stores r_2j - r_2j+1."""
         assert 0 < len(outs) <= G
         merged = []
         for o in outs:
@@ -364,6 +375,13 @@ class Builder:
         pre = []
 
         def fit(f):
+            if subst:
+                k = f.key()
+                if k in subst:
+                    return subst[k]
+                k = (-f).key()
+                if k in subst:
+                    return -subst[k]
             e = encode_form(f)
             if e is not None:
                 return f
@@ -387,14 +405,19 @@ class Builder:
             for a, b in terms:
                 ea, eb = encode_form(a), encode_form(b)
                 assert ea and eb
+                da, db = len(ea) > 4, len(eb) > 4
+                if db and not da:          # the doubling shift exists on the A side only
+                    ea, eb, da, db = eb, ea, True, False
                 a1, a2, asub, b1, b2, bsub = ea[0], ea[1], ea[2], eb[0], eb[1], eb[2]
+                if db:                     # both doubled: B keeps the two-slot form x + x
+                    b2 = b1
                 neg = bool(ea[3]) ^ bool(eb[3])
                 # a sign is free when a form is a difference: -(x - y) = (y - x)
                 if neg and asub:
                     a1, a2, neg = a2, a1, False
                 elif neg and bsub:
                     b1, b2, neg = b2, b1, False
-                enc.append((a1, a2, asub, b1, b2, bsub, neg))
+                enc.append((a1, a2, asub, b1, b2, bsub, neg, da))
             # order every lane's terms alike (plain terms first, negated / two-slot ones last) so that more term
             # positions are uniformly free of negations and second operands across the 12 lanes
             enc.sort(key=lambda x: (bool(x[6]), x[1] != ZERO, x[4] != ZERO))
@@ -406,9 +429,9 @@ class Builder:
         # must stay below 2^63  =>  sum_t La*Lb <= 30.
         for l in lanes:
             budget = 0
-            for (a1, a2, asub, b1, b2, bsub, neg) in l["terms"]:
-                la = 1 if (a2 == ZERO) else 2
-                lb = 1 if (b2 == ZERO) else 2
+            for (a1, a2, asub, b1, b2, bsub, neg, da) in l["terms"]:
+                la = (self.lof(a1) + (self.lof(a2) if a2 != ZERO else 0)) * (2 if da else 1)
+                lb = self.lof(b1) + (self.lof(b2) if b2 != ZERO else 0)
                 budget += la * lb
             assert budget <= 30, "column budget exceeded: %d" % budget
         epi = [(l["alpha"], l["beta"]) != (1, 0) for l in lanes]
@@ -416,8 +439,8 @@ class Builder:
         # value bounds: sum_t Ka*Kb / 2^11 + 1 must stay small; two-slot forms add their slots' bounds
         for l in lanes:
             tot = 0.0
-            for (a1, a2, asub, b1, b2, bsub, neg) in l["terms"]:
-                ka = self.kof(a1) + (self.kof(a2) if a2 != ZERO else 0)
+            for (a1, a2, asub, b1, b2, bsub, neg, da) in l["terms"]:
+                ka = (self.kof(a1) + (self.kof(a2) if a2 != ZERO else 0)) * (2 if da else 1)
                 kb = self.kof(b1) + (self.kof(b2) if b2 != ZERO else 0)
                 tot += ka * kb
             assert tot / 2048 + 1 <= 1.3, "value budget exceeded: %.1f" % tot
@@ -425,7 +448,13 @@ class Builder:
                 assert abs(l["alpha"]) * 1.3 + abs(l["beta"]) * self.kof(l["e"]) < 14
         for l in lanes:
             self.K[l["dst"]] = self.K_VRED if epi[0] else self.K_REDUCED
-        self.steps.append({"op": OP_MULACC, "T": T, "lanes": lanes, "epi": bool(epi[0])})
+            self.L[l["dst"]] = 1
+        if sd:
+            assert len(sd) == len(lanes) == G and all(x is not None for x in sd)
+            for i, l in enumerate(lanes):
+                self.K[sd[i]] = self.K[lanes[i]["dst"]] + self.K[lanes[i ^ 1]["dst"]]
+                self.L[sd[i]] = 2
+        self.steps.append({"op": OP_MULACC, "T": T, "lanes": lanes, "epi": bool(epi[0]), "sd": list(sd) if sd else None})
         self.release(list(temps.values()))
         return T
 
@@ -433,6 +462,7 @@ class Builder:
         """lanes: list of (dst, index).  K_LINE: index = coefficient (0..5) of pair `pair` at the stream
         cursor; K_STATE: index = state element; K_WIRE: index = Fp index in the wire record."""
         for dst, _ in lanes:
+            self.L[dst] = 1
             self.K[dst] = kbound if kbound is not None else (self.K_REDUCED if kind != K_STATE else self.K_INPUT)
         self.steps.append({"op": OP_GLOAD, "kind": kind, "lanes": list(lanes), "advance": advance})
 
@@ -496,8 +526,10 @@ class Builder:
         self.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(flatten12(c0, c1))])
         return V12(d)
 
-    def cyclotomic_sqr(self, dst, a):
-        """Granger-Scott squaring; one MULACC (T = 3) with the 3t +- 2z combination in the epilogue"""
+    def cyclotomic_sqr(self, dst, a, sd_out=None):
+        """Granger-Scott squaring; one MULACC (T = 3) with the 3t +- 2z combination in the epilogue.
+        sd_out: 12 slots that receive the companion sums/differences of the result (x0 + x1, x0 - x1 per Fp2
+        coefficient); when the input carries them (a.sd) every operand form of the step is a stored value."""
         d = self._slots(dst)
         z0, z4, z3, z2, z1, z5 = (a.fp2(j) for j in range(6))
 
@@ -516,8 +548,16 @@ class Builder:
             for c in range(2):
                 i = 2 * j + c
                 outs.append({"dst": d[i], "bil": val[c], "alpha": 3, "beta": beta * a.signs[i], "e": a.slots[i]})
-        self.mulacc(outs)
-        return V12(d)
+        subst = None
+        if a.sd:
+            assert all(sg == 1 for sg in a.signs)
+            subst = {}
+            for j in range(6):
+                x0, x1 = a.lin(2 * j), a.lin(2 * j + 1)
+                subst[(x0 + x1).key()] = Lin.of(a.sd[2 * j])
+                subst[(x0 - x1).key()] = Lin.of(a.sd[2 * j + 1])
+        self.mulacc(outs, subst=subst, sd=sd_out)
+        return V12(d, sd=sd_out)
 
     def frobenius(self, dst, a, power):
         """TRUE Frobenius^power (power in 1..3): coefficient of w^i is conjugated `power` times and
@@ -725,30 +765,42 @@ def prog_fexp_a(from_wire):
     return b
 
 
-def flush_sqr(b, v, n):
+def sqr_run(b, v, n):
+    """n cyclotomic squarings in place.  The run keeps 12 companion slots (x0 + x1, x0 - x1 of every Fp2 coefficient,
+    written by each squaring's epilogue): after the first squaring every operand form of the step is a stored value
+    or a shifted one, so the product loop fetches no second operands."""
     if n <= 0:
         return v
+    sd = b.alloc(12)
+    v = b.cyclotomic_sqr(v, v, sd_out=sd)
     if n > 1:
-        b.loop(n)
-    v = b.cyclotomic_sqr(v, v)
-    if n > 1:
-        b.endloop()
-    return v
+        if n > 2:
+            b.loop(n - 1)
+        v = b.cyclotomic_sqr(v, v, sd_out=sd)
+        if n > 2:
+            b.endloop()
+    b.release(sd)
+    return V12(v.slots)
 
 
-def cyc_exp(b, a):
-    """returns conj(a^|x|) in freshly allocated slots (a in the cyclotomic subgroup; MSB-first over |x|)"""
+def cyc_exp(b, a, park):
+    """-> (conj(a^|x|) in freshly allocated slots, spill handle of a).  a (cyclotomic subgroup) is parked in state area
+    `park` for the whole chain - the squaring runs need its slots for their companions - and filled for the
+    multiplications at the set bits of |x| (MSB first)."""
     bits = bin(M.BLS_X)[2:]
     r = b.copy12(b.alloc(12), a)   # leading one
+    ha = b.spill(a, park)
     run = 0
     for bit in bits[1:]:
         run += 1
         if bit == "1":
-            r = flush_sqr(b, r, run)
+            r = sqr_run(b, r, run)
             run = 0
-            r = b.fp12_mul(r, r, a)
-    r = flush_sqr(b, r, run)
-    return r.conj()
+            av = b.fill(ha)
+            r = b.fp12_mul(r, r, av)
+            b.release(av.slots)
+    r = sqr_run(b, r, run)
+    return r.conj(), ha
 
 
 def prog_fexp_c(to_wire=True):
@@ -790,24 +842,21 @@ def prog_fexp_c(to_wire=True):
     SP = [ST_SPILL + 12 * i for i in range(8)]
     t1 = b.cyclotomic_sqr(u, t2).conj()              # resident: t2 t1
     h1 = b.spill(t1, SP[0])
-    t3 = cyc_exp(b, t2)                              # t2 t3
-    h2 = b.spill(t2, SP[1])
+    t3, h2 = cyc_exp(b, t2, SP[1])                   # t3
     t4 = b.cyclotomic_sqr(b.alloc(12), t3)           # t3 t4
     h4 = b.spill(t4, SP[2])
     t1 = b.fill(h1)                                  # t3 t1
     t5 = b.fp12_mul(t1, t1, t3)                      # t3 t5
     h3 = b.spill(t3, SP[0])
-    t1 = cyc_exp(b, t5)                              # t5 t1
-    h5 = b.spill(t5, SP[3])
-    t0 = cyc_exp(b, t1)                              # t1 t0
-    h1 = b.spill(t1, SP[4])
-    t6 = cyc_exp(b, t0)                              # t0 t6
-    h0 = b.spill(t0, SP[5])
+    t1, h5 = cyc_exp(b, t5, SP[3])                   # t1
+    t0, h1 = cyc_exp(b, t1, SP[4])                   # t0
+    t6, h0 = cyc_exp(b, t0, SP[5])                   # t6
     t4 = b.fill(h4)                                  # t6 t4
     t6 = b.fp12_mul(t6, t6, t4)
     b.release(t4.slots)
-    t4 = cyc_exp(b, t6)                              # t6 t4
+    t4, h6 = cyc_exp(b, t6, SP[7])                   # t4
     h4 = b.spill(t4, SP[2])
+    t6 = b.fill(h6)
     t2 = b.fill(h2)                                  # t6 t2
     t6 = b.fp12_mul(t6, t6, t2.conj())
     t6 = b.frobenius(t6, t6, 1)
@@ -987,11 +1036,13 @@ class Emu:
                 res = []
                 for ln in st["lanes"]:
                     col = [0] * (2 * NL - 1)
-                    for (a1, a2, asub, b1, b2, bsub, neg) in ln["terms"]:
+                    for (a1, a2, asub, b1, b2, bsub, neg, da) in ln["terms"]:
                         a = self.form(a1, a2, asub)
                         b = self.form(b1, b2, bsub)
                         if neg:
                             a = [-x for x in a]
+                        if da:
+                            a = [2 * x for x in a]
                         assert all(abs(x) < (1 << 31) for x in a + b)
                         for i in range(NL):
                             if a[i]:
@@ -1009,6 +1060,10 @@ class Emu:
                     res.append((ln["dst"], out))
                 for d, v in res:
                     self.slot[d] = v
+                if st.get("sd"):
+                    for i, sl in enumerate(st["sd"]):
+                        mine, other = res[i][1], res[i ^ 1][1]
+                        self.slot[sl] = [x + y for x, y in zip(mine, other)] if i % 2 == 0 else [y - x for x, y in zip(mine, other)]
             elif op == OP_LIN:
                 self.counts["lin_steps"] += 1
                 res = []
@@ -1093,15 +1148,20 @@ def encode(builder):
                     if ln is None or t >= len(ln["terms"]):
                         w = ZERO | (ZERO << 7) | (ZERO << 14) | (ZERO << 21)
                     else:
-                        a1, a2, asub, b1, b2, bsub, neg = ln["terms"][t]
-                        w = a1 | (a2 << 7) | (b1 << 14) | (b2 << 21) | (int(asub) << 28) | (int(bsub) << 29) | (int(neg) << 30)
+                        a1, a2, asub, b1, b2, bsub, neg, da = ln["terms"][t]
+                        w = a1 | (a2 << 7) | (b1 << 14) | (b2 << 21) | (int(asub) << 28) | (int(bsub) << 29) | (int(neg) << 30) | (int(da) << 31)
                     tbl.append(w)
-            for ln in lanes_pad(st["lanes"], None):
+            sd = st.get("sd")
+            for li, ln in enumerate(lanes_pad(st["lanes"], None)):
                 if ln is None:
                     tbl.append(0)
                 else:
                     assert -8 <= ln["alpha"] <= 7 and -8 <= ln["beta"] <= 7
-                    tbl.append(ln["dst"] | (1 << 7) | ((ln["alpha"] & 15) << 8) | ((ln["beta"] & 15) << 12) | (ln["e"] << 16))
+                    ew = ln["dst"] | (1 << 7) | ((ln["alpha"] & 15) << 8) | ((ln["beta"] & 15) << 12) | (ln["e"] << 16)
+                    if sd:
+                        assert sd[li] < 64
+                        ew |= (sd[li] << 23) | (1 << 29)
+                    tbl.append(ew)
             no_a2 = no_b2 = 0
             for t in range(T):
                 ts_ = [ln["terms"][t] for ln in st["lanes"] if t < len(ln["terms"])]
@@ -1109,11 +1169,15 @@ def encode(builder):
                     no_a2 |= 1 << t
                 if all(x[4] == ZERO and not x[5] for x in ts_):
                     no_b2 |= 1 << t
-            no_neg = 0
+            no_neg = has_da = 0
             for t in range(T):
                 if not any(ln["terms"][t][6] for ln in st["lanes"] if t < len(ln["terms"])):
                     no_neg |= 1 << t
-            hdr += [op | (T << 8), int(st["epi"]) | (no_neg << 4), off, no_a2 | (no_b2 << 12)]
+                if any(ln["terms"][t][7] for ln in st["lanes"] if t < len(ln["terms"])):
+                    has_da |= 1 << t
+            # word 1: bit 0 epilogue, bit 1 companion (sum/difference) store, bits 4..15 term has no negation,
+            # bits 16..27 term has a doubled A operand in some lane
+            hdr += [op | (T << 8), int(st["epi"]) | (int(bool(sd)) << 1) | (no_neg << 4) | (has_da << 16), off, no_a2 | (no_b2 << 12)]
         elif op == OP_LIN:
             nt = st["nt"]
             for t in range(nt):
@@ -1171,11 +1235,40 @@ def prog_timing(T, epi, nloop=400, lin=False):
             enc = []
             for a_, b_, c_ in o["bil"]:
                 ea, eb = encode_form(a_), encode_form(b_)
-                enc.append((ea[0], ea[1], ea[2], eb[0], eb[1], eb[2], bool(ea[3]) ^ bool(eb[3])))
+                enc.append((ea[0], ea[1], ea[2], eb[0], eb[1], eb[2], bool(ea[3]) ^ bool(eb[3]), False))
             lanes.append({"dst": o["dst"], "terms": enc, "alpha": o.get("alpha", 1), "beta": o.get("beta", 0), "e": o.get("e", ZERO)})
-        b.steps.append({"op": OP_MULACC, "T": T, "lanes": lanes, "epi": bool(epi)})
+        b.steps.append({"op": OP_MULACC, "T": T, "lanes": lanes, "epi": bool(epi), "sd": None})
     b.endloop()
     b.gstore(K_STATE, [(v[i], i) for i in range(12)], spill=True)   # timing only: values are meaningless
+    return b
+
+
+def prog_timing_cyc(companions, nloop=400):
+    """timing only: nloop cyclotomic squarings in place, with or without the companion slots of a squaring run
+    (the values are the state buffer's leftovers: meaningless, but the instruction stream is the real one)"""
+    b = Builder()
+    v = V12(b.alloc(12))
+    b.gload(K_STATE, [(v.slots[i], i) for i in range(12)], kbound=Builder.K_VRED)
+    sd = b.alloc(12) if companions else None
+    if companions:
+        v = b.cyclotomic_sqr(v, v, sd_out=sd)
+    b.loop(nloop)
+    v = b.cyclotomic_sqr(v, v, sd_out=sd)
+    b.endloop()
+    b.gstore(K_STATE, [(v.slots[i], i) for i in range(12)], spill=True)
+    return b
+
+
+def prog_timing_fill(nloop=400):
+    """timing only: nloop x (spill 12 records to the state buffer, fill 12 records from another area)"""
+    b = Builder()
+    v = b.alloc(12)
+    b.gload(K_STATE, [(v[i], i) for i in range(12)])
+    b.loop(nloop)
+    b.gstore(K_STATE, [(v[i], ST_SPILL + i) for i in range(12)], spill=True)
+    b.gload(K_STATE, [(v[i], ST_SPILL + 12 + i) for i in range(12)])
+    b.endloop()
+    b.gstore(K_STATE, [(v[i], i) for i in range(12)], spill=True)
     return b
 
 
@@ -1200,6 +1293,9 @@ PROGRAMS = {
     "time_t6": lambda: prog_timing(6, False),
     "time_t12": lambda: prog_timing(12, False),
     "time_lin": lambda: prog_timing(0, False, lin=True),
+    "time_cyc": lambda: prog_timing_cyc(False),
+    "time_cycsd": lambda: prog_timing_cyc(True),
+    "time_fill": prog_timing_fill,
 }
 
 

@@ -4,8 +4,8 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zkvm_pairings_amd as z
 eng = z.PairingEngine(0)
-n = 1 << 16
-names = ["T=1", "T=3", "T=3+epi", "T=6", "T=12", "LIN"]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 16
+names = ["T=1", "T=3", "T=3+epi", "T=6", "T=12", "LIN", "cyc_sqr", "cyc_sqr+companions", "spill12+fill12"]
 res = {}
 for i, nm in enumerate(names):
     ms = ctypes.c_float()

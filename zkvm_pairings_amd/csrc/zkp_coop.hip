@@ -162,6 +162,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             for (uint32_t t = 0; t < T; t++) {
                 const bool no_a2 = (h3 >> t) & 1, no_b2 = (h3 >> (12 + t)) & 1;   // wave-uniform
                 const bool no_neg = (h1 >> (4 + t)) & 1;                          // no lane negates this term
+                const bool has_da = (h1 >> (16 + t)) & 1;                         // some lane doubles its A operand
                 const int32_t ma = -(int32_t)((w >> 28) & 1), mb = -(int32_t)((w >> 29) & 1), mn = -(int32_t)((w >> 30) & 1);
                 int32_t a[NL], b[NL];
                 if (no_a2 && no_neg) {
@@ -180,6 +181,11 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                     ld(x2, (w >> 7) & 127);
 #pragma unroll
                     for (int i = 0; i < NL; i++) a[i] = ((xa[i] + ((x2[i] ^ ma) - ma)) ^ mn) - mn;
+                }
+                if (has_da) {
+                    const uint32_t sh = w >> 31;
+#pragma unroll
+                    for (int i = 0; i < NL; i++) a[i] = (int32_t)((uint32_t)a[i] << sh);
                 }
                 if (no_b2) {
 #pragma unroll
@@ -210,6 +216,17 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 vred(r);
             }
             if (active && ((ew >> 7) & 1)) lds_st(lds, gbase + (int)(ew & 63), S, r);
+            if (h1 & 2) {  // step-uniform: companion store of a squaring run - the even lane of an Fp2 coefficient keeps
+                           // x0 + x1, the odd lane x0 - x1, so that the next squaring reads its operand forms ready-made
+                int32_t c2[NL];
+                const bool odd = lig & 1;
+#pragma unroll
+                for (int i = 0; i < NL; i++) {
+                    const int32_t o = __builtin_amdgcn_update_dpp(0, r[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+                    c2[i] = odd ? o - r[i] : r[i] + o;
+                }
+                if (active && ((ew >> 29) & 1)) lds_st(lds, gbase + (int)((ew >> 23) & 63), S, c2);
+            }
         } else if (op == OP_LIN) {
             int32_t r[NL];
 #pragma unroll
@@ -1120,8 +1137,9 @@ hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, c
 // timing hook: run one of the synthetic programs (tools/coopgen.py prog_timing) over n checks
 hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, float* ms) {
     CoopDev* d = (CoopDev*)st->d_prog;
-    static const int ids[6] = {ZKP_PROG_TIME_T1, ZKP_PROG_TIME_T3, ZKP_PROG_TIME_T3E, ZKP_PROG_TIME_T6, ZKP_PROG_TIME_T12, ZKP_PROG_TIME_LIN};
-    if (which < 0 || which >= 6) return hipErrorInvalidValue;
+    static const int ids[9] = {ZKP_PROG_TIME_T1, ZKP_PROG_TIME_T3, ZKP_PROG_TIME_T3E, ZKP_PROG_TIME_T6, ZKP_PROG_TIME_T12, ZKP_PROG_TIME_LIN,
+                               ZKP_PROG_TIME_CYC, ZKP_PROG_TIME_CYCSD, ZKP_PROG_TIME_FILL};
+    if (which < 0 || which >= 9) return hipErrorInvalidValue;
     CoopPipe* pp = &d->pipe[0];
     hipError_t e = ensure_buf(&pp->state, &pp->state_bytes, (size_t)ST_SIZE * n * 64);
     if (e != hipSuccess) return e;
