@@ -51,6 +51,9 @@ P_BAL = _balanced(P)                      # balanced limbs of p (|limb| <= 2^27)
 VRED_SHIFT_IN, VRED_SHIFT_OUT = 9, 24
 VRED_C = round((1 << (VRED_SHIFT_IN + VRED_SHIFT_OUT)) / P_BAL[NL - 1])
 LDS_SLOTS = 24         # slots every program must fit: 16 wavefronts of 5 groups share a CU's 160 KB of LDS
+# ... or, for programs that reference at most LDS_WIDE_CONSTS constants, LDS_WIDE_SLOTS slots: the constants region
+# (64 B per constant per wavefront) shrinks by as much as the five groups' extra slots take - same 10,096 B per wavefront
+LDS_WIDE_SLOTS, LDS_WIDE_CONSTS = 30, 4
 G = 12                 # lanes per group
 NSLOT = 64             # group-local slots are 0..NSLOT-1; constants are NSLOT..127
 CONST_BASE = 64
@@ -490,7 +493,19 @@ class Builder:
         self.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(flatten12(c0, c1))])
         return V12(d)
 
-    def fp12_sqr(self, dst, a):
+    def _sd_subst(self, a):
+        """companion slots of a -> substitution table for its sum / difference forms"""
+        if not a.sd:
+            return None
+        assert all(sg == 1 for sg in a.signs)
+        subst = {}
+        for j in range(6):
+            x0, x1 = a.lin(2 * j), a.lin(2 * j + 1)
+            subst[(x0 + x1).key()] = Lin.of(a.sd[2 * j])
+            subst[(x0 - x1).key()] = Lin.of(a.sd[2 * j + 1])
+        return subst
+
+    def fp12_sqr(self, dst, a, sd_out=None):
         """a^2 in ONE accumulation step.  In the basis 1, w, .., w^5 over Fp2 (w^6 = xi; g_j = the Fp2 coefficient of
         w^j) the square is sum_{i<=j} (2 - [i=j]) g_i g_j w^(i+j): every output coefficient sums three or four Fp2
         products (squares as (x0+x1)(x0-x1), 2 x0 x1), i.e. 6-7 Fp products per lane, all operand forms fit the
@@ -511,10 +526,10 @@ class Builder:
                         p = b2_xi(p)
                     acc0, acc1 = acc0 + p[0], acc1 + p[1]
             flat[2 * tw[k]], flat[2 * tw[k] + 1] = acc0, acc1
-        self.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(flat)])
-        return V12(d)
+        self.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(flat)], subst=self._sd_subst(a), sd=sd_out)
+        return V12(d, sd=sd_out)
 
-    def fp12_mul_by_014(self, dst, a, l0, l1, l4):
+    def fp12_mul_by_014(self, dst, a, l0, l1, l4, sd_out=None):
         """a * ((l0 + l1 v) + (l4 v) w)  (reference src/fp12.rs:99-111); l* are Lin pairs"""
         d = self._slots(dst)
         z = (Lin(), Lin())
@@ -523,8 +538,8 @@ class Builder:
         # sparse operand on the A side of every term so that merge_terms groups by its 6 coefficients
         c0 = b6_add(b6_mul(b0, a.fp6(0)), b6_mul_v(b6_mul(b1, a.fp6(1))))
         c1 = b6_add(b6_mul(b1, a.fp6(0)), b6_mul(b0, a.fp6(1)))
-        self.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(flatten12(c0, c1))])
-        return V12(d)
+        self.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(flatten12(c0, c1))], subst=self._sd_subst(a), sd=sd_out)
+        return V12(d, sd=sd_out)
 
     def cyclotomic_sqr(self, dst, a, sd_out=None):
         """Granger-Scott squaring; one MULACC (T = 3) with the 3t +- 2z combination in the epilogue.
@@ -548,15 +563,7 @@ class Builder:
             for c in range(2):
                 i = 2 * j + c
                 outs.append({"dst": d[i], "bil": val[c], "alpha": 3, "beta": beta * a.signs[i], "e": a.slots[i]})
-        subst = None
-        if a.sd:
-            assert all(sg == 1 for sg in a.signs)
-            subst = {}
-            for j in range(6):
-                x0, x1 = a.lin(2 * j), a.lin(2 * j + 1)
-                subst[(x0 + x1).key()] = Lin.of(a.sd[2 * j])
-                subst[(x0 - x1).key()] = Lin.of(a.sd[2 * j + 1])
-        self.mulacc(outs, subst=subst, sd=sd_out)
+        self.mulacc(outs, subst=self._sd_subst(a), sd=sd_out)
         return V12(d, sd=sd_out)
 
     def frobenius(self, dst, a, power):
@@ -632,7 +639,7 @@ def emit_line_mul(b, f, k):
         l0 = lin2(tmp6[0], tmp6[1])
         l1 = lin2(tmp6[2], tmp6[3])
         l4 = lin2(tmp6[4], tmp6[5])
-        f = b.fp12_mul_by_014(f, f, l0, l1, l4)
+        f = b.fp12_mul_by_014(f, f, l0, l1, l4, sd_out=f.sd)
     b.release(tmp6)
     return f
 
@@ -644,6 +651,10 @@ def prog_miller(k, to_wire):
     f = b.alloc12()
     one = CONST_SLOT["ONE"]
     b.lin([(f.slots[i], Lin.of(one if i == 0 else ZERO)) for i in range(12)])
+    # the accumulator keeps companion slots (x0 + x1, x0 - x1 of every Fp2 coefficient), rewritten by every step's
+    # epilogue: the steps' operand forms are then stored or shifted values.  30 slots: a "wide" program (few constants)
+    f.sd = b.alloc(12)
+    b.lin([(f.sd[i], Lin.of(one if i < 2 else ZERO)) for i in range(12)])
     for n_plain, has_add in runs(miller_bits()):
         # iterations: [dbl-line, square] * (n_plain - 1), then [dbl-line, (add-line), square]
         body_plain = n_plain - 1 if has_add else n_plain
@@ -651,14 +662,15 @@ def prog_miller(k, to_wire):
             if body_plain > 1:
                 b.loop(body_plain)
             f = emit_line_mul(b, f, k)
-            f = b.fp12_sqr(f, f)
+            f = b.fp12_sqr(f, f, sd_out=f.sd)
             if body_plain > 1:
                 b.endloop()
         if has_add:
             f = emit_line_mul(b, f, k)
             f = emit_line_mul(b, f, k)
-            f = b.fp12_sqr(f, f)
+            f = b.fp12_sqr(f, f, sd_out=f.sd)
     f = emit_line_mul(b, f, k)
+    b.release(f.sd)
     finish_output(b, f.conj(), to_wire, ST_F)
     return b
 
@@ -1299,11 +1311,20 @@ PROGRAMS = {
 }
 
 
+def lds_config(peak, nconst):
+    """0: LDS_SLOTS slots + all constants; 1: LDS_WIDE_SLOTS slots + LDS_WIDE_CONSTS constants (same LDS bytes)"""
+    if peak <= LDS_SLOTS:
+        return 0
+    assert peak <= LDS_WIDE_SLOTS and nconst <= LDS_WIDE_CONSTS, (peak, nconst)
+    return 1
+
+
 def write_inc(path):
     lines = ["// GENERATED by tools/coopgen.py - do not edit.  Step programs of the lane-cooperative kernels.",
              "#pragma once", "#include <stdint.h>",
              "#define ZKP_COOP_G %d" % G, "#define ZKP_COOP_NSLOT_MAX %d" % NSLOT, "#define ZKP_COOP_NSLOT %d" % LDS_SLOTS,
-             "#define ZKP_COOP_NCONST %d" % N_CONST, "#define ZKP_COOP_ST_SIZE %d" % ST_SIZE,
+             "#define ZKP_COOP_NCONST %d" % N_CONST, "#define ZKP_COOP_WIDE_NSLOT %d" % LDS_WIDE_SLOTS, "#define ZKP_COOP_WIDE_NCONST %d" % LDS_WIDE_CONSTS,
+             "#define ZKP_COOP_ST_SIZE %d" % ST_SIZE,
              "#define ZKP_COOP_ST_G %d" % ST_G, "#define ZKP_COOP_ST_N %d" % ST_N, "#define ZKP_COOP_ST_NINV %d" % ST_NINV,
              "#define ZKP_COOP_NLINES %d" % n_line_steps(),
              "#define ZKP_COOP_VRED_C %d" % VRED_C, "#define ZKP_COOP_VRED_SHIFT_IN %d" % VRED_SHIFT_IN,
@@ -1334,11 +1355,13 @@ def write_inc(path):
                 for _, terms in st["lanes"]:
                     used += [sl for sl, _ in terms]
         nconst = max(x for x in used if x >= CONST_BASE) - CONST_BASE + 1
-        meta.append((n, len(hdr), len(tbl), b.peak, nconst))
-    lines.append("struct ZkpProgDesc { const uint32_t* hdr; uint32_t n_hdr; const uint32_t* tbl; uint32_t n_tbl; uint32_t nslot; uint32_t nconst; };")
+        wide = lds_config(b.peak, nconst)
+        meta.append((n, len(hdr), len(tbl), b.peak, nconst, wide))
+    lines.append("// wide: the program runs with ZKP_COOP_WIDE_NSLOT slots and ZKP_COOP_WIDE_NCONST constants instead of ZKP_COOP_NSLOT / ZKP_COOP_NCONST")
+    lines.append("struct ZkpProgDesc { const uint32_t* hdr; uint32_t n_hdr; const uint32_t* tbl; uint32_t n_tbl; uint32_t nslot; uint32_t nconst; uint32_t wide; };")
     lines.append("static const ZkpProgDesc ZKP_PROGS[ZKP_PROG_COUNT] = {")
-    for n, nh, nt, peak, nconst in meta:
-        lines.append("  {ZKP_PROG_%s_HDR, %d, ZKP_PROG_%s_TBL, %d, %d, %d}," % (n.upper(), nh, n.upper(), max(1, nt), peak, nconst))
+    for n, nh, nt, peak, nconst, wide in meta:
+        lines.append("  {ZKP_PROG_%s_HDR, %d, ZKP_PROG_%s_TBL, %d, %d, %d, %d}," % (n.upper(), nh, n.upper(), max(1, nt), peak, nconst, wide))
     lines.append("};")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
@@ -1347,6 +1370,6 @@ def write_inc(path):
 
 if __name__ == "__main__":
     out = os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_coop_prog.inc")
-    for n, nh, nt, peak, nconst in write_inc(out):
-        print("%-16s steps=%4d table_words=%6d peak_slots=%d consts=%d" % (n, nh // 4, nt, peak, nconst))
+    for n, nh, nt, peak, nconst, wide in write_inc(out):
+        print("%-16s steps=%4d table_words=%6d peak_slots=%d consts=%d%s" % (n, nh // 4, nt, peak, nconst, " (wide)" if wide else ""))
     print("wrote", out)

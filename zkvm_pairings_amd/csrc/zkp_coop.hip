@@ -113,6 +113,9 @@ __device__ __forceinline__ void canon28(uint32_t* f, const int32_t* x) {
 #ifndef ZKP_COOP_WAVES
 #define ZKP_COOP_WAVES 4   // 128 VGPRs; with 24-slot programs 16 waves fit a CU (LDS 8-10 KB per wave)
 #endif
+// S slots per group and SC constants: two instantiations with the same LDS footprint (10,096 B per wavefront) -
+// <24, 34> for programs that need the whole constants table, <30, 4> for the Miller programs (30 slots, 4 constants)
+template <int S, int SC>
 __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     extern __shared__ int4 lds[];
     const int lane = threadIdx.x;
@@ -121,9 +124,8 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     const bool lane_ok = grp < GROUPS;
     const uint32_t check = blockIdx.x * GROUPS + grp;
     const bool active = lane_ok && check < A.n_checks;
-    // compile-time plane strides: the q * stride offsets fold into the ds_read/ds_write immediates
-    constexpr int S = ZKP_COOP_NSLOT;          // every generated program fits this many slots
-    constexpr int SC = ZKP_COOP_NCONST;        // plane stride of the constants region (A.nconst of them are uploaded)
+    // S, SC: compile-time plane strides (the q * stride offsets fold into the ds_read/ds_write immediates); A.nconst
+    // of the SC constants are uploaded
     const int cbase = 0;
     const int gbase = 4 * SC + (lane_ok ? grp : GROUPS - 1) * (4 * S + 3);
 
@@ -842,7 +844,7 @@ __global__ void k_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint6
 // =============================================================================== host side
 namespace zkp {
 
-struct CoopProgDev { uint32_t* hdr; uint32_t* tbl; uint32_t nslot; uint32_t nconst; };
+struct CoopProgDev { uint32_t* hdr; uint32_t* tbl; uint32_t nslot; uint32_t nconst; uint32_t wide; };
 constexpr int MAX_PIPES = 4;
 struct CoopPipe {            // one in-flight chunk: its own workspace and (for pipes > 0) its own stream
     int4* lines;  size_t lines_bytes;
@@ -878,6 +880,7 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
         if ((e = hipMemcpy(d->progs[i].tbl, p.tbl, p.n_tbl * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
         d->progs[i].nslot = p.nslot;
         d->progs[i].nconst = p.nconst;
+        d->progs[i].wide = p.wide;
     }
     if ((e = hipMalloc((void**)&d->consts, sizeof(ZKP_COOP_CONSTS))) != hipSuccess) return e;
     if ((e = hipMemcpy(d->consts, ZKP_COOP_CONSTS, sizeof(ZKP_COOP_CONSTS), hipMemcpyHostToDevice)) != hipSuccess) return e;
@@ -959,16 +962,24 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     a.n_checks = n_checks;
     a.nc = nc;
     a.k = k;
-    if (d->progs[prog].nslot > (uint32_t)ZKP_COOP_NSLOT) return hipErrorInvalidValue;
-    a.S = ZKP_COOP_NSLOT;
+    const bool wide = d->progs[prog].wide != 0;
+    if (d->progs[prog].nslot > (uint32_t)(wide ? ZKP_COOP_WIDE_NSLOT : ZKP_COOP_NSLOT) ||
+        d->progs[prog].nconst > (uint32_t)(wide ? ZKP_COOP_WIDE_NCONST : ZKP_COOP_NCONST))
+        return hipErrorInvalidValue;
+    a.S = wide ? ZKP_COOP_WIDE_NSLOT : ZKP_COOP_NSLOT;
     a.nconst = d->progs[prog].nconst;
     a.st_off = st_off;
     a.chk_off = chk_off;
+    static_assert(4 * ZKP_COOP_NCONST + GROUPS * (4 * ZKP_COOP_NSLOT + 3) == 4 * ZKP_COOP_WIDE_NCONST + GROUPS * (4 * ZKP_COOP_WIDE_NSLOT + 3),
+                  "both LDS configurations must have the same footprint");
     size_t lds_bytes = (size_t)(4 * ZKP_COOP_NCONST + GROUPS * (4 * ZKP_COOP_NSLOT + 3)) * 16;
     static const char* pad_env = getenv("ZKP_COOP_LDS_PAD");   // occupancy experiments only
     if (pad_env) lds_bytes += (size_t)atol(pad_env);
     unsigned blocks = (n_checks + GROUPS - 1) / GROUPS;
-    hipLaunchKernelGGL(k_coop, dim3(blocks), dim3(64), lds_bytes, s, a);
+    if (wide)
+        hipLaunchKernelGGL((k_coop<ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST>), dim3(blocks), dim3(64), lds_bytes, s, a);
+    else
+        hipLaunchKernelGGL((k_coop<ZKP_COOP_NSLOT, ZKP_COOP_NCONST>), dim3(blocks), dim3(64), lds_bytes, s, a);
     return hipGetLastError();
 }
 
