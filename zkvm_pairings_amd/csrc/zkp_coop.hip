@@ -132,7 +132,10 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     for (int i = lane; i < (int)A.nconst * 4; i += 64) lds[(i & 3) * SC + (i >> 2)] = A.consts[i];
     __syncthreads();
 
-    const uint32_t* __restrict__ hdr = A.hdr;
+    // the step headers are read-only and wave-uniform: through the constant address space they become scalar loads
+    // (s_load_dwordx4 into SGPRs, scalar cache) instead of a vector load + readfirstlane per word
+    typedef const __attribute__((address_space(4))) uint32_t* chdr_t;
+    chdr_t hdr = (chdr_t)(uintptr_t)A.hdr;
     const uint32_t* __restrict__ tbl = A.tbl;
     uint32_t cursor = 0;
     int pc = 0, loop_pc = 0, loop_left = 0;
@@ -140,15 +143,13 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     auto ld = [&](int32_t* x, uint32_t s) { lds_ld(x, lds, slot_off(s), (s & 64) ? SC : S); };
 
     for (;;) {
-        const uint32_t h0 = __builtin_amdgcn_readfirstlane(hdr[4 * pc]);
-        const uint32_t h1 = __builtin_amdgcn_readfirstlane(hdr[4 * pc + 1]);
-        const uint32_t off = __builtin_amdgcn_readfirstlane(hdr[4 * pc + 2]);
+        const uint32_t h0 = hdr[4 * pc], h1 = hdr[4 * pc + 1], off = hdr[4 * pc + 2];
         const uint32_t op = h0 & 0xff, arg = (h0 >> 8) & 0xff;
         if (op == OP_END) break;
         if (op == OP_MULACC) {
             // software pipeline: table words two terms ahead, LDS operands one term ahead, so the
             // 196 multiply-adds of term t cover the latency of everything term t+1 needs
-            const uint32_t h3 = __builtin_amdgcn_readfirstlane(hdr[4 * pc + 3]);
+            const uint32_t h3 = hdr[4 * pc + 3];
             const uint32_t T = arg;
             Acc acc;
             acc_zero(acc);
