@@ -449,6 +449,8 @@ class Builder:
             assert tot / 2048 + 1 <= 1.3, "value budget exceeded: %.1f" % tot
             if epi[0]:
                 assert abs(l["alpha"]) * 1.3 + abs(l["beta"]) * self.kof(l["e"]) < 14
+                # limbs of alpha r + beta e - q p before the single weak normalisation: (|alpha| + |beta| + |q|) 2^27 < 2^31
+                assert abs(l["alpha"]) + abs(l["beta"]) + abs(l["alpha"]) * 1.3 + abs(l["beta"]) * self.kof(l["e"]) + 1 < 15
         for l in lanes:
             self.K[l["dst"]] = self.K_VRED if epi[0] else self.K_REDUCED
             self.L[l["dst"]] = 1
@@ -951,20 +953,18 @@ def acc_reduce(col):
             assert abs(col[i + j]) < (1 << 63), "column overflow in reduction"
         assert col[i] & ((1 << W) - 1) == 0
         col[i + 1] += col[i] >> W
-    # limb k = lo_k + mid_{k-1} + top_{k-2} from the signed 64-bit columns c[14..26], then weak_norm
-    lo, mid, top = [], [], []
+    # carry-propagate the signed 64-bit columns c[14..26] into balanced 28-bit limbs (the top limb keeps the rest)
+    out = []
+    v = col[NL]
     for k in range(NL - 1):
-        v = col[NL + k]
-        assert abs(v) < (1 << 63)
-        lo.append(v & ((1 << W) - 1))
-        mid.append((v >> W) & ((1 << W) - 1))
-        top.append(v >> (2 * W))
-    out = [lo[0], lo[1] + mid[0]]
-    for k in range(2, NL - 1):
-        out.append(lo[k] + mid[k - 1] + top[k - 2])
-    out.append(mid[NL - 2] + top[NL - 3] + (top[NL - 2] << W))
+        assert abs(v) < (1 << 63) - (1 << W)
+        t = v + (1 << (W - 1))
+        out.append((t & ((1 << W) - 1)) - (1 << (W - 1)))
+        v = col[NL + k + 1] + (t >> W)
+    assert abs(v) < (1 << 31)
+    out.append(v)
     assert limbs_value(out) == sum(col[NL + k] << (W * k) for k in range(NL - 1))
-    return weak_norm(out)
+    return out
 
 
 def weak_norm(x):
@@ -989,6 +989,17 @@ def vred(x):
     assert abs(q) <= 14, "value too large for vred (q = %d)" % q
     y = [a - q * b for a, b in zip(x, P_BAL)]
     y = weak_norm(y)
+    assert abs(limbs_value(y)) < 0.51 * P
+    return y
+
+
+def epilogue(r, e, alpha, beta):
+    """alpha r + beta e, renormalised, exactly as the kernel's MULACC epilogue: q from the top limb of the
+    combination, x = alpha r + beta e - q p limb-wise, ONE weak_norm"""
+    t = alpha * r[NL - 1] + beta * e[NL - 1]
+    q = ((t >> VRED_SHIFT_IN) * VRED_C + (1 << (VRED_SHIFT_OUT - 1))) >> VRED_SHIFT_OUT
+    assert abs(q) <= 14, "value too large for the epilogue (q = %d)" % q
+    y = weak_norm([alpha * a + beta * b - q * c for a, b, c in zip(r, e, P_BAL)])
     assert abs(limbs_value(y)) < 0.51 * P
     return y
 
@@ -1066,9 +1077,11 @@ class Emu:
                     assert mx < (1 << 62), "column overflow in accumulation (%d bits)" % mx.bit_length()
                     r = acc_reduce(col)
                     e = self.slot[ln["e"]]
-                    out = [ln["alpha"] * x + ln["beta"] * y for x, y in zip(r, e)]
                     if st["epi"]:
-                        out = vred(weak_norm(out))
+                        out = epilogue(r, e, ln["alpha"], ln["beta"])
+                    else:
+                        assert (ln["alpha"], ln["beta"]) == (1, 0)
+                        out = r
                     res.append((ln["dst"], out))
                 for d, v in res:
                     self.slot[d] = v

@@ -213,10 +213,13 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 int32_t e[NL];
                 ld(e, (ew >> 16) & 127);
                 const int32_t al = sext4((ew >> 8) & 15), be = sext4((ew >> 12) & 15);
+                // value renormalisation folded in: q = round(value / p) from the top limb of the combination
+                // (the lower limbs are normalised: their carries cannot move q), then ONE weak normalisation
+                const int32_t top = al * r[NL - 1] + be * e[NL - 1];
+                const int32_t q = ((top >> ZKP_COOP_VRED_SHIFT_IN) * ZKP_COOP_VRED_C + (1 << (ZKP_COOP_VRED_SHIFT_OUT - 1))) >> ZKP_COOP_VRED_SHIFT_OUT;
 #pragma unroll
-                for (int i = 0; i < NL; i++) r[i] = al * r[i] + be * e[i];
+                for (int i = 0; i < NL; i++) r[i] = al * r[i] + be * e[i] - q * K_PBAL[i];
                 weak_norm(r);
-                vred(r);
             }
             if (active && ((ew >> 7) & 1)) lds_st(lds, gbase + (int)(ew & 63), S, r);
             if (h1 & 2) {  // step-uniform: companion store of a squaring run - the even lane of an Fp2 coefficient keeps

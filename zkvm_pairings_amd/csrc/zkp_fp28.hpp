@@ -50,9 +50,9 @@ __device__ __forceinline__ int32_t lo28s(int64_t v) { return ((int32_t)((uint32_
 
 // Montgomery reduction of the accumulated columns (divides by 2^392), then limb extraction.
 // Result value = acc * 2^-392 mod p, in (acc/R, acc/R + p).
-// The 13 surviving columns c[14..26] are signed 64-bit; each splits exactly into lo (28 bits, unsigned)
-// + mid (28 bits, unsigned) * 2^28 + top (signed 8 bits) * 2^56, so limb k = lo_k + mid_{k-1} + top_{k-2}:
-// three 32-bit adds per limb, no 64-bit carry chain.  A one-pass weak normalisation makes them balanced.
+// The 13 surviving columns c[14..26] are signed 64-bit; a carry chain turns them into balanced 28-bit limbs
+// (|limb| <= 2^27, the top limb keeps whatever is left): five instructions per column and no normalisation pass
+// afterwards (the three-way lo/mid/top split it replaces needed seven plus a weak_norm).
 __device__ __forceinline__ void weak_norm(int32_t* x);
 __device__ __forceinline__ void acc_reduce(int32_t* out, Acc& acc) {
 #pragma unroll
@@ -62,20 +62,14 @@ __device__ __forceinline__ void acc_reduce(int32_t* out, Acc& acc) {
         for (int j = 0; j < NL; j++) acc.c[i + j] += (int64_t)(int32_t)m * (int64_t)K28_P[j];
         acc.c[i + 1] += acc.c[i] >> W;  // low 28 bits of c[i] are now zero
     }
-    int32_t lo[NL], mid[NL], top[NL];
+    int64_t v = acc.c[NL];
 #pragma unroll
     for (int k = 0; k < NL - 1; k++) {
-        const int64_t v = acc.c[NL + k];
-        lo[k] = (int32_t)((uint32_t)v & (uint32_t)MASK);
-        mid[k] = (int32_t)((uint32_t)(v >> W) & (uint32_t)MASK);
-        top[k] = (int32_t)(v >> (2 * W));
+        const int64_t t = v + (1ll << (W - 1));
+        out[k] = (int32_t)((uint32_t)t & (uint32_t)MASK) - (1 << (W - 1));
+        v = acc.c[NL + k + 1] + (t >> W);   // c[27] is the empty carry sink
     }
-    out[0] = lo[0];
-    out[1] = lo[1] + mid[0];
-#pragma unroll
-    for (int k = 2; k < NL - 1; k++) out[k] = lo[k] + mid[k - 1] + top[k - 2];
-    out[NL - 1] = mid[NL - 2] + top[NL - 3] + (top[NL - 2] << W);
-    weak_norm(out);
+    out[NL - 1] = (int32_t)v;
 }
 
 // one-pass weak normalisation of limb-wise sums: |in| < 2^31  ->  |out| <= 2^27 + 16
