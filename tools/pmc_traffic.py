@@ -22,7 +22,7 @@ PASS_KERNELS = ("k_prep_lines", "k_coop", "k_batch_inv")
 
 def short(name):
     for k in PASS_KERNELS + ("k_g1_mul28", "k_g2_mul28"):
-        if k + "(" in name:
+        if k + "(" in name or k + "<" in name:      # k_coop is a template: k_coop<24, 34>(...)
             return k
     return name.split("(")[0]
 
