@@ -24,6 +24,12 @@ extern "C" {
     pub fn zkp_final_exponentiation_batch(ctx: *mut ZkpCtx, f: *const u64, n: usize, out_gt: *mut u64) -> c_int;
     pub fn zkp_pairing_check_batch(ctx: *mut ZkpCtx, g1: *const u64, g2: *const u64, inf1: *const u8,
                                    inf2: *const u8, n_checks: usize, k: usize, ok: *mut u8, all_ok: *mut c_int) -> c_int;
+    /// the whole batch as ONE product check: Miller product over all n pairs, Fp12 product, one final exponentiation
+    pub fn zkp_miller_product(ctx: *mut ZkpCtx, g1: *const u64, g2: *const u64, inf1: *const u8, inf2: *const u8,
+                              n: usize, out_ml: *mut u64) -> c_int;
+    pub fn zkp_fp12_product(ctx: *mut ZkpCtx, f: *const u64, n: usize, out: *mut u64) -> c_int;
+    pub fn zkp_pairing_product_check(ctx: *mut ZkpCtx, g1: *const u64, g2: *const u64, inf1: *const u8,
+                                     inf2: *const u8, n: usize, out_gt: *mut u64, is_one: *mut c_int) -> c_int;
     pub fn zkp_g1_is_valid_batch(ctx: *mut ZkpCtx, g1: *const u64, inf: *const u8, n: usize, status: *mut u8) -> c_int;
     pub fn zkp_g2_is_valid_batch(ctx: *mut ZkpCtx, g2: *const u64, inf: *const u8, n: usize, status: *mut u8) -> c_int;
     pub fn zkp_pairing_batch_dev(ctx: *mut ZkpCtx, d_g1: *const c_void, d_g2: *const c_void, d_inf1: *const c_void,
