@@ -389,7 +389,18 @@ __device__ __attribute__((noinline)) Fp28 c_sqr(Fp28 mine, int c) {
     return r;
 }
 // r = coefficient c of (a0 + a1 u)(b0 + b1 u) :  c=0: a0 b0 - a1 b1 ;  c=1: a0 b1 + a1 b0  (one reduction)
-__device__ __attribute__((noinline)) Fp28 c_mul(Fp28 ma, Fp28 mb, int c) {
+// The second operand of the by-value routines travels as four int4 vectors: clang's AMDGPU ABI passes aggregates in
+// registers only while they total at most 16 registers, so a second Fp28 (14 registers) went through the stack - a
+// scratch store in the caller and a load the callee had to wait for, at every call.
+__device__ __forceinline__ void fp28_unpack(Fp28& x, const int4& q0, const int4& q1, const int4& q2, const int4& q3) {
+    x.l[0] = q0.x; x.l[1] = q0.y; x.l[2] = q0.z; x.l[3] = q0.w; x.l[4] = q1.x; x.l[5] = q1.y; x.l[6] = q1.z; x.l[7] = q1.w;
+    x.l[8] = q2.x; x.l[9] = q2.y; x.l[10] = q2.z; x.l[11] = q2.w; x.l[12] = q3.x; x.l[13] = q3.y;
+}
+#define FP28_AS_QUADS(x) make_int4((x).l[0], (x).l[1], (x).l[2], (x).l[3]), make_int4((x).l[4], (x).l[5], (x).l[6], (x).l[7]), \
+                         make_int4((x).l[8], (x).l[9], (x).l[10], (x).l[11]), make_int4((x).l[12], (x).l[13], 0, 0)
+__device__ __attribute__((noinline)) Fp28 c_mul_q(Fp28 ma, int4 q0, int4 q1, int4 q2, int4 q3, int c) {
+    Fp28 mb;
+    fp28_unpack(mb, q0, q1, q2, q3);
     Fp28 ao, bo, r;
     swap_pair(ao, ma);
     swap_pair(bo, mb);
@@ -406,11 +417,14 @@ __device__ __attribute__((noinline)) Fp28 c_mul(Fp28 ma, Fp28 mb, int c) {
     acc_reduce(r.l, acc);
     return r;
 }
-__device__ __attribute__((noinline)) Fp28 f_mul_v(Fp28 a, Fp28 b) {
-    Fp28 r;
+__device__ __forceinline__ Fp28 c_mul(const Fp28& ma, const Fp28& mb, int c) { return c_mul_q(ma, FP28_AS_QUADS(mb), c); }
+__device__ __attribute__((noinline)) Fp28 f_mul_q(Fp28 a, int4 q0, int4 q1, int4 q2, int4 q3) {
+    Fp28 b, r;
+    fp28_unpack(b, q0, q1, q2, q3);
     fp28_mul(r, a, b);
     return r;
 }
+__device__ __forceinline__ Fp28 f_mul_v(const Fp28& a, const Fp28& b) { return f_mul_q(a, FP28_AS_QUADS(b)); }
 __device__ __forceinline__ Fp28 c_add(const Fp28& a, const Fp28& b) { Fp28 r; f_add(r, a, b); return r; }
 __device__ __forceinline__ Fp28 c_sub(const Fp28& a, const Fp28& b) { Fp28 r; f_sub(r, a, b); return r; }
 __device__ __forceinline__ Fp28 c_dbl(const Fp28& a) { Fp28 r; f_add(r, a, a); return r; }
@@ -435,17 +449,18 @@ __device__ __forceinline__ void dbl_step(G2C& r, int c, S0&& sink_l0, S1&& sink_
     nz = c_sub(c_sub(nz, tmp1), zsq);
     Fp28 tmp0 = c_sqr(r.x, c);
     Fp28 tmp4 = c_add(c_add(tmp0, tmp0), tmp0);
-    Fp28 tmp6 = c_add(r.x, tmp4);
+    Fp28 tmp5 = c_sqr(tmp4, c);
+    {
+        Fp28 tmp6 = c_sqr(c_add(r.x, tmp4), c);
+        tmp6 = c_sub(c_sub(tmp6, tmp0), tmp5);
+        sink_l2(c_sub(tmp6, c_dbl(c_dbl(tmp1))));
+    }
     Fp28 tmp3 = c_sqr(c_add(tmp1, r.x), c);
     Fp28 tmp2 = c_sqr(tmp1, c);
     tmp3 = c_dbl(c_sub(c_sub(tmp3, tmp0), tmp2));
     sink_l1(c_neg(c_dbl(c_mul(tmp4, zsq, c))));
     sink_l0(c_dbl(c_mul(nz, zsq, c)));
-    Fp28 tmp5 = c_sqr(tmp4, c);
     Fp28 nx = c_sub(c_sub(tmp5, tmp3), tmp3);
-    tmp6 = c_sqr(tmp6, c);
-    tmp6 = c_sub(c_sub(tmp6, tmp0), tmp5);
-    sink_l2(c_sub(tmp6, c_dbl(c_dbl(tmp1))));
     Fp28 ny = c_mul(c_sub(tmp3, nx), tmp4, c);
     ny = c_sub(ny, c_dbl(c_dbl(c_dbl(tmp2))));
     vred(nx.l); vred(ny.l); vred(nz.l);
