@@ -10,8 +10,13 @@
 //                    MULACC  sum of <=12 products into 64-bit columns, ONE Montgomery reduction
 //                    LIN     limb-wise linear combination (no carries), weak normalisation
 //                    GLOAD/GSTORE  line stream / per-check state / wire format
+//                  the optional epilogue (alpha r + beta E, renormalised) and the companion store
+//                  (x0 + x1 / x0 - x1 of the lane pair's Fp2 coefficient, so that later steps fetch their
+//                  operand forms ready-made) ride on the MULACC step.
 //   k_batch_inv    the single Fp inversion of the final exponentiation, up to 32 checks per lane (Montgomery's trick).
-// Programs: miller{k}_{state|wire}, fexp_a_{state|wire}, fexp_c (zkp_coop_prog.inc).
+// Programs: miller{k}_{state|wire}, f12mul_{state|wire|pairs}, fexp_a_{state|wire}, fexp_c (zkp_coop_prog.inc).
+// Host side: a super-chunk of up to 2^20 checks shares one state buffer; phase A (lines, Miller loop, fexp_a) runs per
+// 2^16-check chunk on two HIP streams, then ONE k_batch_inv and ONE fexp_c launch cover the super-chunk (two_phase).
 //
 // Reference anchors: Fp12::mul_by_014 src/fp12.rs:99-111, Fp12::square :173-184, Fp12::invert
 // :186-190 (+ src/fp6.rs:291-309, src/fp2.rs:278-296), conjugate :123-125; pairing semantics
