@@ -884,6 +884,7 @@ struct CoopDev {
     size_t chunk;            // checks per pipeline pass (bounds the line-stream workspace: 26 KB per pair)
     size_t super;            // checks per two-phase final exponentiation (one batched inversion for all of them)
     bool c_single;           // phase C as one launch per large super-chunk (default) or always per chunk on the pipelines
+    size_t c_single_min;     // ... "large" = more checks than this
     uint32_t inv_batch;      // most checks one lane inverts together (Montgomery's trick)
     size_t inv_lanes;        // ... and the number of lanes the inversion kernel keeps busy before it batches
     int4* big_state;         // per-check state of a whole super-chunk (7.9 KB per check)
@@ -922,6 +923,8 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     if (d->super < d->chunk) d->super = d->chunk;
     ev = getenv("ZKP_COOP_C_SINGLE");
     d->c_single = ev ? atoi(ev) != 0 : true;
+    ev = getenv("ZKP_COOP_C_SINGLE_MIN");
+    d->c_single_min = ev ? (size_t)atol(ev) : 4 * d->chunk;
     ev = getenv("ZKP_COOP_INV_BATCH");
     d->inv_batch = ev ? (uint32_t)atoi(ev) : 32;
     if (d->inv_batch < 1) d->inv_batch = 1;
@@ -1124,7 +1127,7 @@ static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_line
         if ((e = hipGetLastError()) != hipSuccess) return e;
         // phase C needs no line buffer: one launch over a large super-chunk has no per-chunk tails (-1 % at 2^20
         // checks); small ones do better per chunk on the two pipelines (-1 % at 2^17)
-        if (d->c_single && ns > 4 * d->chunk) {
+        if (d->c_single && ns > d->c_single_min) {
             CoopPipe v = d->pipe[0];
             v.state = d->big_state;
             v.stream = s;
