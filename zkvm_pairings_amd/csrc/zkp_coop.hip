@@ -921,6 +921,7 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     ev = getenv("ZKP_COOP_SUPER");
     d->super = ev ? (size_t)atol(ev) : ((size_t)1 << 20);
     if (d->super < d->chunk) d->super = d->chunk;
+    if (d->super > ((size_t)1 << 22)) d->super = (size_t)1 << 22;   // 33 GB of state; keeps every per-launch count in 32 bits
     ev = getenv("ZKP_COOP_C_SINGLE");
     d->c_single = ev ? atoi(ev) != 0 : true;
     ev = getenv("ZKP_COOP_C_SINGLE_MIN");
