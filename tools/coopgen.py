@@ -1306,6 +1306,14 @@ PROGRAMS = {
     "miller3_wire": lambda: prog_miller(3, True),
     "miller4_state": lambda: prog_miller(4, False),
     "miller4_wire": lambda: prog_miller(4, True),
+    "miller5_state": lambda: prog_miller(5, False),
+    "miller5_wire": lambda: prog_miller(5, True),
+    "miller6_state": lambda: prog_miller(6, False),
+    "miller6_wire": lambda: prog_miller(6, True),
+    "miller7_state": lambda: prog_miller(7, False),
+    "miller7_wire": lambda: prog_miller(7, True),
+    "miller8_state": lambda: prog_miller(8, False),
+    "miller8_wire": lambda: prog_miller(8, True),
     "f12mul_pairs": prog_f12mul_pairs,
     "f12mul_state": lambda: prog_f12mul(False),
     "f12mul_wire": lambda: prog_f12mul(True),

@@ -506,7 +506,7 @@ __device__ __forceinline__ void add_step(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, c
 
 // two lanes per pair: write the 68-step line stream of pair `pid` (check = pid / k, j = pid % k);
 // lane c writes the records of Fp2 coefficient c.  The k pairs are pairs j0 .. j0+k-1 of the check's k_in
-// input pairs (k_in > k when a check is processed in groups of at most four pairs).
+// input pairs (k_in > k when a check is processed in groups of at most eight pairs).
 #ifndef ZKP_PREP_WAVES
 #define ZKP_PREP_WAVES 2   // measured: 256 VGPRs (2 waves/SIMD) 6.6 ms, 168 -> 9.3 ms, 128 -> 11.4 ms per 2^17 pairs (spill traffic)
 #endif
@@ -1017,11 +1017,15 @@ static int miller_prog(size_t k, bool wire) {
         case 2: return wire ? ZKP_PROG_MILLER2_WIRE : ZKP_PROG_MILLER2_STATE;
         case 3: return wire ? ZKP_PROG_MILLER3_WIRE : ZKP_PROG_MILLER3_STATE;
         case 4: return wire ? ZKP_PROG_MILLER4_WIRE : ZKP_PROG_MILLER4_STATE;
+        case 5: return wire ? ZKP_PROG_MILLER5_WIRE : ZKP_PROG_MILLER5_STATE;
+        case 6: return wire ? ZKP_PROG_MILLER6_WIRE : ZKP_PROG_MILLER6_STATE;
+        case 7: return wire ? ZKP_PROG_MILLER7_WIRE : ZKP_PROG_MILLER7_STATE;
+        case 8: return wire ? ZKP_PROG_MILLER8_WIRE : ZKP_PROG_MILLER8_STATE;
         default: return -1;
     }
 }
 
-constexpr size_t MAX_GROUP = 4;   // pairs per Miller program; a check with more pairs is processed in groups
+constexpr size_t MAX_GROUP = 8;   // pairs per Miller program (shared squarings); a check with more pairs is processed in groups
 bool coop_supports_k(size_t k) { return k >= 1 && k <= 0xffffu; }
 
 // line stream of pairs j0 .. j0+g-1 of each of the n checks starting at base_check (k_in pairs per check)
@@ -1035,8 +1039,8 @@ static hipError_t prep(CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, con
     return hipGetLastError();
 }
 
-// multi_miller_loop of n checks of k pairs each on one pipeline.  k <= 4: one program.  k > 4: groups of at most
-// four pairs run their own Miller loop (the line buffer is reused), the group values are joined by f12mul
+// multi_miller_loop of n checks of k pairs each on one pipeline.  k <= 8: one program.  k > 8: groups of at most
+// eight pairs run their own Miller loop (the line buffer is reused), the group values are joined by f12mul
 // (prod_i f_i is the multi-Miller value; only the shared squarings are lost).  Result: state ST_F, or the
 // canonical wire record in `wire_out` when that is not null.
 static hipError_t miller_on_pipe(CoopDev* d, CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2,
@@ -1069,6 +1073,10 @@ static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lin
     if (!n_total) return hipSuccess;
     hipError_t e;
     size_t chunk = d->chunk;
+    if (need_lines && k > 4) {   // keep the line buffer at the size four pairs per check need
+        chunk = chunk * 4 / (k < MAX_GROUP ? k : MAX_GROUP);
+        if (chunk < 320) chunk = 320;
+    }
     int pipes = d->n_pipes;
     if (n_total <= chunk) pipes = 1;
     // workspace first: hipMalloc/hipFree synchronise the device, so never (re)allocate between launches

@@ -19,7 +19,7 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop);
 void coop_free(CoopState* st);
 // true when `kind` (zkp_kernel_kind) routes the pairing path through the cooperative kernels
 bool coop_selected(const CoopState* st, int kind);
-// pairs per check the cooperative path takes (checks with more than four pairs run in groups of four)
+// pairs per check the cooperative path takes (checks with more than eight pairs run in groups of eight)
 bool coop_supports_k(size_t k);
 // test hook: 28-bit-limb Montgomery multiply on wire operands
 hipError_t coop_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, hipStream_t s);

@@ -353,7 +353,7 @@ int miller_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t
                uint64_t* out, hipStream_t s) {
     if (n_checks == 0) return ZKP_OK;
     if (k >= 64 && n_checks <= 16) {
-        // few checks with long term lists: spread each check's pairs over the GPU (four per accumulator) and fold the
+        // few checks with long term lists: spread each check's pairs over the GPU (eight per accumulator) and fold the
         // values with the product tree, instead of walking the check's groups one after the other
         for (size_t ck = 0; ck < n_checks; ck++) {
             int rc = miller_product_dev(c, g1 + 12 * ck * k, g2 + 24 * ck * k, i1 ? i1 + ck * k : nullptr, i2 ? i2 + ck * k : nullptr, k,
@@ -426,16 +426,17 @@ int fp12_product_dev(zkp_ctx* c, const uint64_t* f, size_t n, uint64_t* out, hip
     return ZKP_OK;
 }
 
-// multi_miller_loop over the whole batch as ONE check: the pairs are taken four at a time (one shared accumulator
-// per four pairs), the n/4 values are multiplied by the product tree.  Result left in c->prod[0..72) and copied to out.
+// multi_miller_loop over the whole batch as ONE check: the pairs are taken eight at a time (one shared accumulator
+// per eight pairs), the n/8 values are multiplied by the product tree.  Result left in c->prod[0..72) and copied to out.
 int miller_product_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n, uint64_t* out,
                        hipStream_t s) {
     if (n == 0) { HIPCHK(c, hipMemcpyAsync(out, GT_IDENTITY, 576, hipMemcpyHostToDevice, s)); return ZKP_OK; }
-    const size_t n4 = n / 4, r = n % 4, nv = n4 + (r ? 1 : 0);
+    constexpr size_t PG = 8;   // pairs per accumulator
+    const size_t n4 = n / PG, r = n % PG, nv = n4 + (r ? 1 : 0);
     int rc = ensure_prod(c, nv);
     if (rc) return rc;
-    if (n4 && (rc = miller_dev(c, g1, g2, i1, i2, n4, 4, c->prod, s))) return rc;
-    if (r && (rc = miller_dev(c, g1 + 12 * 4 * n4, g2 + 24 * 4 * n4, i1 ? i1 + 4 * n4 : nullptr, i2 ? i2 + 4 * n4 : nullptr, 1, r,
+    if (n4 && (rc = miller_dev(c, g1, g2, i1, i2, n4, PG, c->prod, s))) return rc;
+    if (r && (rc = miller_dev(c, g1 + 12 * PG * n4, g2 + 24 * PG * n4, i1 ? i1 + PG * n4 : nullptr, i2 ? i2 + PG * n4 : nullptr, 1, r,
                               c->prod + 72 * n4, s)))
         return rc;
     if ((rc = fp12_product_inplace(c, c->prod, nv, s))) return rc;
@@ -446,10 +447,10 @@ int miller_product_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const
 // prod_i e(P_i, Q_i) == Gt::identity() with ONE final exponentiation; out_gt and is_one are device pointers, each optional
 int product_check_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n, uint64_t* out_gt,
                       int* is_one, hipStream_t s) {
-    int rc = ensure_prod(c, n / 4 + 1);
+    int rc = ensure_prod(c, n / 8 + 1);
     if (rc) return rc;
     if ((rc = miller_product_dev(c, g1, g2, i1, i2, n, n ? nullptr : c->prod, s))) return rc;
-    const size_t nv = n / 4 + (n % 4 ? 1 : 0);
+    const size_t nv = n / 8 + (n % 8 ? 1 : 0);
     uint64_t* gt = c->prod + 72 * (nv + 1);      // spare record (ensure_prod keeps two)
     if ((rc = final_exp_dev(c, c->prod, 1, gt, s))) return rc;
     if (out_gt) HIPCHK(c, hipMemcpyAsync(out_gt, gt, 576, hipMemcpyDeviceToDevice, s));
