@@ -398,6 +398,29 @@ def test_host_pointer_entry_points_in_slices(monkeypatch):
         e.close()
 
 
+def test_divstep_inversion_equals_fermat(monkeypatch):
+    """the final exponentiation's Fp inversion: division steps (default) against a^(p-2) (ZKP_COOP_INV_FERMAT=1) on the
+    same inputs, one check per lane and several per lane; zero inputs give the same (unspecified but equal) results"""
+    from zkvm_pairings_amd import PairingEngine, synthetic
+    outs = []
+    for fermat, lanes in (("0", "1000000"), ("1", "1000000"), ("0", "16"), ("1", "16")):
+        monkeypatch.setenv("ZKP_COOP_INV_FERMAT", fermat)
+        monkeypatch.setenv("ZKP_COOP_INV_LANES", lanes)
+        e = PairingEngine(0, kernel="coop")
+        try:
+            if not outs:
+                g1, g2, _, _ = synthetic.random_pairs(e, 777, seed=31)
+                ml = e.multi_miller_loop(g1, g2, 1)
+                ml[[3, 500]] = 0
+            outs.append(e.final_exponentiation(ml))
+        finally:
+            e.close()
+    assert all(np.array_equal(outs[0], x) for x in outs[1:])
+    keep = np.ones(777, dtype=bool)
+    keep[[3, 500]] = False
+    assert np.array_equal(outs[0][keep][:64], o.final_exponentiation_batch(ml[keep][:64]))
+
+
 def test_simultaneous_inversion_paths(monkeypatch):
     """the final exponentiation's batched Fp inversion with several checks per lane (Montgomery's trick), ragged
     tail included; a zero (non-invertible) input must not disturb the checks that share its lane."""
