@@ -113,3 +113,13 @@ def test_program_encoding_is_consistent():
         cg.write_inc(tf.name)
         with open(os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_coop_prog.inc")) as f:
             assert f.read() == open(tf.name).read(), "run tools/coopgen.py to regenerate zkp_coop_prog.inc"
+
+
+def test_division_step_inversion_model():
+    """tools/safegcd_model.py: the limb-exact model of the kernels' Fp inversion (f_inv in zkp_coop.hip) against pow(x, -1, p);
+    its constants are the ones tools/gen_constants.py writes into zkp_constants28.h"""
+    import safegcd_model as sgm
+    assert sgm.selftest(n=300)
+    hdr = open(os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_constants28.h")).read()
+    assert "#define ZKP30_PINV %du" % sgm.PINV30 in hdr
+    assert "#define ZKP30_P_LIMBS %s" % ", ".join(str(x) for x in sgm.PL) in hdr
