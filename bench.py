@@ -144,7 +144,7 @@ def main():
                          "achieved": achieved / 1e12, "peak": PEAK_MACS / 1e12, "unit": "T u32-MAC/s",
                          "frac": achieved / PEAK_MACS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_macs_per_pairing": MACS_PER_PAIRING,
-                         "launch": "one pass over the resident batch = phase A per 2^16-check chunk on two overlapped HIP streams (k_prep_lines, k_coop miller, k_coop fexp_a), ONE k_batch_inv and ONE k_coop fexp_c launch over the whole shard; kernel_ms is that pass timed with HIP events on the launching stream (profiles/r01/v17_pass_timeline.txt)"},
+                         "launch": "one pass over the resident batch = phase A per 2^16-check chunk on two overlapped HIP streams (k_prep_lines, k_coop miller, k_coop fexp_a), ONE k_batch_inv and ONE k_coop fexp_c launch over the whole shard; kernel_ms is that pass timed with HIP events on the launching stream (profiles/r01/v18_pass_timeline.txt)"},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
