@@ -487,8 +487,8 @@ int ensure_slot(zkp_ctx* c, zkp_ctx::HostSlot* h, int which, size_t bytes) {
 // pairing()/pairing check of n_checks x k pairs from HOST arrays in slices: while slice i computes on the context's
 // stream, the host thread uploads slice i+1 (copy-in stream) and downloads the results of slice i-1 (copy-out stream).
 // out_gt / ok / all_ok are host pointers, each optional.
-int host_sliced(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks, size_t k,
-                uint64_t* out_gt, uint8_t* ok, int* all_ok) {
+int host_sliced_impl(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks, size_t k,
+                     uint64_t* out_gt, uint8_t* ok, int* all_ok) {
     const size_t sc = c->host_slice / k ? c->host_slice / k : 1;   // checks per slice
     const size_t nsl = (n_checks + sc - 1) / sc;
     int rc;
@@ -554,6 +554,18 @@ int host_sliced(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_
     return ZKP_OK;
 }
 
+// an error must not leave copies from / into the caller's arrays in flight
+int host_sliced(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks, size_t k,
+                uint64_t* out_gt, uint8_t* ok, int* all_ok) {
+    const int rc = host_sliced_impl(c, g1, g2, inf1, inf2, n_checks, k, out_gt, ok, all_ok);
+    if (rc != ZKP_OK) {
+        if (c->s_in) (void)hipStreamSynchronize(c->s_in);
+        (void)hipStreamSynchronize(c->stream);
+        if (c->s_out) (void)hipStreamSynchronize(c->s_out);
+    }
+    return rc;
+}
+
 // copy a (g1,g2,inf1,inf2) pair batch to workspace slots 0..3
 int stage_pairs(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t np, Staged* st) {
     int rc;
@@ -577,6 +589,15 @@ int stage_pairs(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_
     return ZKP_OK;
 }
 
+}  // namespace
+
+// Host-pointer entry points copy from / into the caller's arrays asynchronously: whatever way such a call returns
+// (HIPCHK included), nothing may still be in flight - the context's stream is drained on the way out.
+namespace {
+struct HostCall {
+    zkp_ctx* c;
+    ~HostCall() { if (c && c->stream) (void)hipStreamSynchronize(c->stream); }
+};
 }  // namespace
 
 // =============================================================================== C ABI
@@ -784,6 +805,7 @@ int zkp_pairing_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const 
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
+    HostCall drain{c};
     if (n > c->host_slice && !c->validate) return host_sliced(c, g1, g2, inf1, inf2, n, 1, out_gt, nullptr, nullptr);
     Staged st;
     if ((rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st)) || (rc = ensure(c, 4, n * 576))) return rc;
@@ -798,6 +820,7 @@ int zkp_multi_miller_loop_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* 
     if (!n_checks) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
+    HostCall drain{c};
     Staged st = {nullptr, nullptr, nullptr, nullptr};
     if (k && (rc = stage_pairs(c, g1, g2, inf1, inf2, n_checks * k, &st))) return rc;
     if ((rc = ensure(c, 4, n_checks * 576))) return rc;
@@ -811,6 +834,7 @@ int zkp_final_exponentiation_batch(zkp_ctx* c, const uint64_t* f, size_t n, uint
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
+    HostCall drain{c};
     if ((rc = ensure(c, 5, n * 576)) || (rc = ensure(c, 4, n * 576))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->buf[5], f, n * 576, hipMemcpyHostToDevice, c->stream));
     if ((rc = validate_dev(c, (const uint64_t*)c->buf[5], n * 12))) return rc;
@@ -824,6 +848,7 @@ int zkp_fp12_product(zkp_ctx* c, const uint64_t* f, size_t n, uint64_t* out) {
     if (!n) { memcpy(out, GT_IDENTITY, 576); return ZKP_OK; }
     int rc = bind(c);
     if (rc) return rc;
+    HostCall drain{c};
     if ((rc = ensure_prod(c, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->prod, f, n * 576, hipMemcpyHostToDevice, c->stream));
     if ((rc = validate_dev(c, c->prod, n * 12))) return rc;
@@ -837,6 +862,7 @@ int zkp_miller_product(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const
     if (!n) { memcpy(out_ml, GT_IDENTITY, 576); return ZKP_OK; }
     int rc = bind(c);
     if (rc) return rc;
+    HostCall drain{c};
     Staged st = {nullptr, nullptr, nullptr, nullptr};
     if ((rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st))) return rc;
     if ((rc = miller_product_dev(c, st.g1, st.g2, st.i1, st.i2, n, nullptr, c->stream))) return rc;
@@ -854,6 +880,7 @@ int zkp_pairing_product_check(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2
     }
     int rc = bind(c);
     if (rc) return rc;
+    HostCall drain{c};
     Staged st = {nullptr, nullptr, nullptr, nullptr};
     if ((rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st))) return rc;
     if ((rc = ensure(c, 4, 576))) return rc;
@@ -872,6 +899,7 @@ int zkp_pairing_check_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, 
     if (!n_checks) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
+    HostCall drain{c};
     // flags-only results need no large download: one shot is faster (measured) until the upload workspace gets large
     if (k && n_checks * k > 8 * c->host_slice && !c->validate) return host_sliced(c, g1, g2, inf1, inf2, n_checks, k, nullptr, ok, all_ok);
     Staged st = {nullptr, nullptr, nullptr, nullptr};
@@ -890,6 +918,7 @@ static int valid_host(zkp_ctx* c, int which, const uint64_t* pts, const uint8_t*
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
+    HostCall drain{c};
     size_t sz = which == 1 ? 96 : 192;
     if ((rc = ensure(c, 0, n * sz)) || (rc = ensure(c, 6, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->buf[0], pts, n * sz, hipMemcpyHostToDevice, c->stream));
@@ -916,6 +945,7 @@ static int mul_host(zkp_ctx* c, int which, const uint64_t* base, size_t stride, 
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
+    HostCall drain{c};
     size_t nb = stride ? n : 1;
     if ((rc = ensure(c, 0, nb * w * 8)) || (rc = ensure(c, 1, n * 32)) || (rc = ensure(c, 4, n * w * 8)) || (rc = ensure(c, 6, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->buf[0], base, nb * w * 8, hipMemcpyHostToDevice, c->stream));
@@ -940,6 +970,7 @@ static int codec_host(zkp_ctx* c, bool decode, int nfp, const void* in, const ui
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
+    HostCall drain{c};
     const size_t nb = n * 48 * nfp;
     if ((rc = ensure(c, 0, nb)) || (rc = ensure(c, 4, nb)) || (rc = ensure(c, 2, n)) || (rc = ensure(c, 6, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->buf[0], in, nb, hipMemcpyHostToDevice, c->stream));
@@ -981,6 +1012,7 @@ int zkp_fp_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, si
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
+    HostCall drain{c};
     if ((rc = ensure(c, 0, n * 48)) || (rc = ensure(c, 1, n * 48)) || (rc = ensure(c, 4, n * 48))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->buf[0], a, n * 48, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->buf[1], b, n * 48, hipMemcpyHostToDevice, c->stream));
