@@ -1026,6 +1026,7 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     st->cus = prop.multiProcessorCount;
     CoopDev* d = new CoopDev();
     memset(d, 0, sizeof(*d));
+    st->d_prog = d;          // coop_free releases whatever exists if the initialisation stops half way
     hipError_t e;
     for (int i = 0; i < ZKP_PROG_COUNT; i++) {
         const ZkpProgDesc& p = ZKP_PROGS[i];
@@ -1069,7 +1070,6 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
         if ((e = hipEventCreateWithFlags(&d->pipe[i].done, hipEventDisableTiming)) != hipSuccess) return e;
     }
     if ((e = hipEventCreateWithFlags(&d->ready, hipEventDisableTiming)) != hipSuccess) return e;
-    st->d_prog = d;
     st->available = true;
     return hipSuccess;
 }

@@ -630,11 +630,11 @@ int zkp_init(int device, zkp_ctx** out_ctx) {
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess || hipMalloc((void**)&c->d_flag, 2 * sizeof(int)) != hipSuccess) {
-        delete c;
+        zkp_free(c);
         return ZKP_ERR_NO_DEVICE;
     }
     if (zkp::coop_init(&c->coop, c->prop) != hipSuccess) {
-        delete c;
+        zkp_free(c);
         return ZKP_ERR_HIP;
     }
     if (const char* hsl = getenv("ZKP_HOST_SLICE")) {
