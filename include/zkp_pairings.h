@@ -15,7 +15,11 @@
  *   zkp_g2_is_valid_batch           G2Affine::is_valid                       src/g2.rs:57-69  (:109-120, :166-170)
  *   zkp_g1_mul_batch / g2           &G1Affine * &Fr / &G2Affine * &Fr         src/g1.rs:130-153 (bit-0 bug F5 NOT
  *                                                                            mirrored), src/g2.rs:185-208
- *   zkp_fp_op_batch                 bls12381_sys_bigint(out, op, a, b)       src/fp.rs:376,443 (op 0 = mul, 1 = add)
+ *   zkp_fp_op_batch                 bls12381_sys_bigint(out, op, a, b)       src/fp.rs:376,443 (op 0 = mul, 1 = add); also
+ *                                   Fp::sub / neg / square / invert          src/fp.rs:307-319, 383-411, 453-455
+ *   zkp_tower_op_batch              Fp2 / Fp6 / Fp12 mul, square, mul_by_014, src/fp2.rs:171-209, src/fp6.rs:188-288,
+ *                                   conjugate, frobenius_map (the TRUE map)   src/fp12.rs:99-210 (:143-170 is wrong)
+ *   zkp_pairing_*_multi             the same pairing()/check over several GPUs from ONE host thread
  *
  * Wire formats (all little-endian, canonical representatives in [0,p), identical to the
  * reference's in-memory structs):
@@ -31,7 +35,9 @@
  * aborts and never unwinds across this boundary (the reference's panics F7 become status bytes).
  * Inputs must be canonical (< p): non-canonical limbs give ZKP_ERR_NONCANONICAL when validation is on
  * (zkp_set_validate), unspecified field values otherwise.
- * Threading: a zkp_ctx is bound to one GPU and is not thread-safe; use one ctx per thread / rank.
+ * Threading: a zkp_ctx is bound to one GPU and is not thread-safe; use one ctx per thread / rank.  The *_dev calls
+ * of one ctx may be issued on different streams: each call first makes its stream wait (an event, no host wait) for the
+ * previous call's use of the context's workspace, so they never overlap on it.
  * There is NO CPU fallback: zkp_init fails with ZKP_ERR_NO_DEVICE when no gfx950 device is usable.
  */
 #ifndef ZKP_PAIRINGS_H
@@ -54,6 +60,37 @@ typedef enum {
     ZKP_ERR_NONCANONICAL = -4, /* an input limb array is >= p (validation mode) */
     ZKP_ERR_OOM = -5
 } zkp_status;
+
+/* zkp_fp_op_batch: the operation in bits 0..3, the limb core in bit 4.  0 and 1 are the op numbers of the zkVM precompile
+ * bls12381_sys_bigint (src/fp.rs:376,443); unary operations ignore b (may be NULL). */
+typedef enum {
+    ZKP_FP_MUL = 0,
+    ZKP_FP_ADD = 1,
+    ZKP_FP_SUB = 2,
+    ZKP_FP_NEG = 3,
+    ZKP_FP_SQUARE = 4,
+    ZKP_FP_INVERT = 5,      /* 0 gives 0 (the reference returns None, src/fp.rs:307-319) */
+    ZKP_FP_CORE28 = 16      /* OR-ed in: run on the 14 x 28-bit carry-free core of the cooperative family instead of
+                               the 12 x 32-bit Montgomery core */
+} zkp_fp_op;
+
+/* zkp_tower_op_batch: one tower operation per 72-u64 record.  Smaller tower elements occupy the leading coefficients
+ * of a record (Fp2: 12 u64, Fp6: 36 u64); the rest of an input must be zero and the rest of the result is zero. */
+typedef enum {
+    ZKP_TOWER_FP2_MUL = 0,
+    ZKP_TOWER_FP2_SQUARE = 1,
+    ZKP_TOWER_FP6_MUL = 2,
+    ZKP_TOWER_FP6_SQUARE = 3,
+    ZKP_TOWER_FP6_FROBENIUS = 4,            /* x^p (NOT what src/fp6.rs:142-176 computes) */
+    ZKP_TOWER_FP12_MUL = 5,
+    ZKP_TOWER_FP12_SQUARE = 6,
+    ZKP_TOWER_FP12_MUL_BY_014 = 7,          /* b = c0 | c1 | c4 (three Fp2) in the first 36 u64 of its record */
+    ZKP_TOWER_FP12_FROBENIUS = 8,           /* x^p */
+    ZKP_TOWER_FP12_CONJUGATE = 9,
+    ZKP_TOWER_FP12_CYCLOTOMIC_SQUARE = 10,  /* Granger-Scott; input in the cyclotomic subgroup */
+    ZKP_TOWER_FP12_CYCLOTOMIC_POW2K = 11    /* g^(2^repeat), 1 <= repeat <= 64: compressed squarings + decompression
+                                               (the building block of the final exponentiation's x-power chains) */
+} zkp_tower_op;
 
 /* which Miller-loop/final-exp kernel family the context uses */
 typedef enum {
@@ -119,8 +156,11 @@ int zkp_g2_decode_batch(zkp_ctx* ctx, const uint8_t* bytes, size_t n, uint64_t* 
 int zkp_g1_encode_batch(zkp_ctx* ctx, const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* out_bytes);
 int zkp_g2_encode_batch(zkp_ctx* ctx, const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* out_bytes);
 
-/* batched field op in the zkVM precompile shape: op 0 = mul, 1 = add (src/fp.rs:376,443) */
+/* batched field op in the zkVM precompile shape (op: zkp_fp_op; 0 = mul and 1 = add as in src/fp.rs:376,443) */
 int zkp_fp_op_batch(zkp_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* batched tower operation (op: zkp_tower_op) on the context's kernel family; a, b, out: n records of 72 u64; b is read
+ * only by the binary operations; repeat only by ZKP_TOWER_FP12_CYCLOTOMIC_POW2K. */
+int zkp_tower_op_batch(zkp_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint32_t repeat, uint64_t* out);
 
 /* ---- device-pointer entry points (buffers already resident in HBM; asynchronous on `stream`) ---- */
 /* `stream` is a hipStream_t passed as void* (NULL = default stream).  Same formats as above. */
@@ -150,6 +190,26 @@ int zkp_g1_mul_batch_dev(zkp_ctx* ctx, const void* d_base, size_t base_stride, c
                          void* d_out, void* d_out_inf, void* stream);
 int zkp_g2_mul_batch_dev(zkp_ctx* ctx, const void* d_base, size_t base_stride, const void* d_scalars, size_t n,
                          void* d_out, void* d_out_inf, void* stream);
+
+/* validation mode (zkp_set_validate) on the device-pointer entry points: the range check of the inputs runs on the caller's
+ * stream and ORs into a word inside the context - no host synchronisation in the *_dev call itself.  This call waits for
+ * `stream`, reports whether any *_dev call since the last query saw a field element >= p (*bad = 1; the results of such a
+ * call are unspecified) and clears the word. */
+int zkp_take_validation_status_dev(zkp_ctx* ctx, void* stream, int* bad);
+
+/* ---- several GPUs behind one call ------------------------------------------------------------------
+ * ONE host thread, n_ctx distinct contexts (normally one per GPU of the node, each from zkp_init(device)); the checks
+ * are split into contiguous blocks, one per context (a check's k pairs and its shared final exponentiation stay
+ * on one GPU), every context uploads, computes and downloads its block on its own stream concurrently, and the
+ * per-context AND flags are combined on the host - the data path has no collective.  Host pointers, synchronous,
+ * same formats and results as zkp_pairing_check_batch / zkp_pairing_batch + the Gt::identity() flags.
+ * The one-process-per-GPU form (torchrun / MPI ranks) is zkp_pairing_check_batch per rank followed by ONE
+ * ncclAllReduce(&flag, &flag, 1, ncclInt32, ncclMin, comm, stream): RCCL has no bitwise AND, MIN of {0,1} is AND. */
+int zkp_pairing_check_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1,
+                                  const uint8_t* inf2, size_t n_checks, size_t k, uint8_t* ok /* may be NULL */, int* all_ok);
+/* out_gt[i] = pairing(g1[i], g2[i]); ok[i] = (out_gt[i] == Gt::identity()) and *all_ok, each optional */
+int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1,
+                            const uint8_t* inf2, size_t n, uint64_t* out_gt, uint8_t* ok, int* all_ok);
 
 /* ---- measurement helper used by bench.py: times `reps` launches of the fused pairing kernel on
  * ctx's own stream with HIP events recorded on THAT stream; returns average ms per launch. ---- */

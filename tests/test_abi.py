@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), "libzkp_pairings.so does not export %s" % n
         assert n in _lib.SIGNATURES, "python binding table lacks %s" % n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.zkp_abi_version() == 1
+    assert lib.zkp_abi_version() == 2
 
 
 def test_gt_identity_and_strerror():

@@ -22,7 +22,7 @@ def run_pairing(pairs):
     ea = cg.Emu(state=state).run(cg.prog_fexp_a(False).steps)
     n = cg.from_mont(ea.state[cg.ST_N])
     ea.state[cg.ST_NINV] = cg.mont(m.fp_inv(n))       # the batched inversion kernel's job
-    ec = cg.Emu(state=ea.state).run(cg.prog_fexp_c(True).steps)
+    ec = cg.run_plan(cg.fexp_c_plan(), ea.state)
     return f_true, ec, (em, ea)
 
 
@@ -33,9 +33,9 @@ def test_emulated_pairing_of_generators_matches_model():
     assert ec.wire_out == m.f12_flat_ints(m.final_exponentiation(ml))
     assert ec.is_identity is False
     # headroom of the lazy accumulation: columns must stay well inside 63 bits
-    assert max(em.max_col, ec.max_col).bit_length() <= 61
-    # step census used by DESIGN.md
-    assert em.counts["mulacc_steps"] > 100 and ec.counts["mulacc_steps"] > 300
+    assert max(em.max_col, ec.plan_stats["max_col"]).bit_length() <= 61
+    # step census used by DESIGN.md: the x-power chains' 315 squarings run in k_ksq, not on the interpreter
+    assert em.counts["mulacc_steps"] > 100 and 40 < ec.plan_stats["mulacc_steps"] < 80
 
 
 def test_emulated_wire_roundtrip_and_three_pair_check(model_vectors):
@@ -49,7 +49,7 @@ def test_emulated_wire_roundtrip_and_three_pair_check(model_vectors):
     ea = cg.Emu(wire_in=em.wire_out).run(cg.prog_fexp_a(True).steps)
     n = cg.from_mont(ea.state[cg.ST_N])
     ea.state[cg.ST_NINV] = cg.mont(m.fp_inv(n))
-    ec = cg.Emu(state=ea.state).run(cg.prog_fexp_c(True).steps)
+    ec = cg.run_plan(cg.fexp_c_plan(), ea.state)
     assert ec.wire_out == [1] + [0] * 11 and ec.is_identity is True
 
 
@@ -88,6 +88,85 @@ def test_fp12_product_tree_level(model_vectors):
     one = [1] + [0] * 11
     assert cg.Emu(wire_in=a, wire_in2=one).run(cg.prog_f12mul_pairs().steps).wire_out == a
     assert cg.Emu(wire_in=one, wire_in2=g).run(cg.prog_f12mul_pairs().steps).wire_out == g
+
+
+def _cyclotomic(seed):
+    g = m.SplitMix64(seed)
+    f = [(g.below(m.P), g.below(m.P)) for _ in range(6)]
+    t0 = f
+    for _ in range(6):
+        t0 = m.f12_frob(t0)
+    t2 = m.f12_mul(t0, m.f12_inv(f))
+    return m.f12_mul(m.f12_frob(m.f12_frob(t2)), t2)
+
+
+def _state_of(v12, base):
+    return {base + i: cg.mont(x) for i, x in enumerate(m.f12_flat_ints(v12))}
+
+
+def test_compressed_squaring_run_and_decompression():
+    """k_ksq / k_kdec_a / k_kdec_b (limb-exact models): snapshots of a compressed squaring run, completed by the
+    decompression, equal g^(2^e); the identity (all four coefficients zero) and z2 == 0 take the 0 / 0 := 0 route."""
+    g = _cyclotomic(77)
+    state = _state_of(g, 0)
+    mask = (1 << 0) | (1 << 2) | (1 << 6)
+    cg.emu_ksq(state, 0, cg.ST_SNAP, 7, mask)
+    cg.emu_kdec_a(state, cg.ST_SNAP, 3, cg.ST_KN)
+    cg.emu_inv(state, cg.ST_KN, cg.ST_KNINV, 3)
+    cg.emu_kdec_b(state, cg.ST_SNAP, 3, cg.ST_KNINV)
+    h, want = g, {}
+    for e in range(1, 8):
+        h = m.f12_sqr(h)
+        want[e] = m.f12_flat_ints(h)
+    for k, e in enumerate((1, 3, 7)):
+        got = [cg.from_mont(state[cg.ST_SNAP + 12 * k + i]) for i in range(12)]
+        assert got == want[e], (k, e)
+    # the identity: compressed form (0, 0, 0, 0) -> decompression gives 1
+    one = m.f12_one()
+    state = _state_of(one, 0)
+    cg.emu_ksq(state, 0, cg.ST_SNAP, 3, 1 << 2)
+    cg.emu_kdec_a(state, cg.ST_SNAP, 1, cg.ST_KN)
+    cg.emu_inv(state, cg.ST_KN, cg.ST_KNINV, 1)
+    cg.emu_kdec_b(state, cg.ST_SNAP, 1, cg.ST_KNINV)
+    assert [cg.from_mont(state[cg.ST_SNAP + i]) for i in range(12)] == [1] + [0] * 11
+    # the plan's mask is the set bits of |x|
+    assert cg.X_BITS == [16, 48, 57, 60, 62, 63] and cg.KSQ_NSQ == 63
+
+
+def test_tower_op_programs_match_model():
+    """the zkp_tower_op_batch programs (direct hooks for Fp2 / Fp6 / Fp12 primitives) against the big-int model"""
+    g = m.SplitMix64(4242)
+    rnd = lambda: [g.below(m.P) for _ in range(12)]
+    a, b = rnd(), rnd()
+    A, B = m.f12_from_flat_ints(a), m.f12_from_flat_ints(b)
+    run = lambda op, x, y=None: cg.Emu(wire_in=x, wire_in2=y).run(cg.prog_tower(op).steps).wire_out
+    assert run("fp12_mul", a, b) == m.f12_flat_ints(m.f12_mul(A, B))
+    assert run("fp12_sqr", a) == m.f12_flat_ints(m.f12_sqr(A))
+    assert run("fp12_frob", a) == m.f12_flat_ints(m.f12_frob(A))
+    assert run("fp12_conj", a) == m.f12_flat_ints(m.f12_conj(A))
+    c0, c1, c4 = (b[0], b[1]), (b[2], b[3]), (b[4], b[5])
+    assert run("fp12_014", a, b) == m.f12_flat_ints(m.f12_mul(A, m._sparse_014(c0, c1, c4)))
+    pad = lambda v: list(v) + [0] * (12 - len(v))
+    f2 = lambda v: (v[0], v[1])
+    assert run("fp2_mul", pad(a[:2]), pad(b[:2])) == pad(m.f2_mul(f2(a), f2(b)))
+    assert run("fp2_sqr", pad(a[:2])) == pad(m.f2_sqr(f2(a)))
+    f6 = lambda v: ((v[0], v[1]), (v[2], v[3]), (v[4], v[5]))
+    flat6 = lambda t: [c for pr in t for c in pr]
+    assert run("fp6_mul", pad(a[:6]), pad(b[:6])) == pad(flat6(m.f6_mul(f6(a), f6(b))))
+    assert run("fp6_sqr", pad(a[:6])) == pad(flat6(m.f6_mul(f6(a), f6(a))))
+    assert run("fp12_frob", pad(a[:6]))[:6] == flat6(m.f6_frob_true(f6(a)))
+    cyc = m.f12_flat_ints(_cyclotomic(9))
+    assert run("cyc_sqr", cyc) == m.f12_flat_ints(m.f12_sqr(m.f12_from_flat_ints(cyc)))
+    # wire -> state -> (k_ksq, decompression) -> wire: g^(2^5)
+    st = cg.Emu(wire_in=cyc).run(cg.prog_tower_to_state().steps).state
+    cg.emu_ksq(st, 0, cg.ST_SNAP, 5, 1 << 4)
+    cg.emu_kdec_a(st, cg.ST_SNAP, 1, cg.ST_KN)
+    cg.emu_inv(st, cg.ST_KN, cg.ST_KNINV, 1)
+    cg.emu_kdec_b(st, cg.ST_SNAP, 1, cg.ST_KNINV)
+    h = m.f12_from_flat_ints(cyc)
+    for _ in range(5):
+        h = m.f12_sqr(h)
+    assert cg.Emu(state=st).run(cg.prog_tower_from_snap().steps).wire_out == m.f12_flat_ints(h)
 
 
 def test_program_encoding_is_consistent():

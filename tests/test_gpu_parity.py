@@ -59,7 +59,84 @@ def test_fp_op_precompile_shape(eng):
     assert o.arr_to_ints(add) == [(x + y) % m.P for x, y in zip(ai, bi)]
     assert eng.fp_op(0, a[:0], b[:0]).shape == (0, 6)
     # op 2: the same product through the 28-bit carry-free core of the cooperative kernel family
-    assert np.array_equal(eng.fp_op(2, a, b), mul)
+    assert np.array_equal(eng.fp_op("mul", a, b, core28=True), mul)
+
+
+@pytest.mark.parametrize("core28", [False, True])
+def test_fp_ops_direct_on_both_limb_cores(eng, core28):
+    """Fp::mul / add / sub / neg / square / invert (reference src/fp.rs:307-319, 352-455) through zkp_fp_op_batch on the
+    12 x 32-bit core and on the 14 x 28-bit core, against the oracle and against Python integers."""
+    n = 1024
+    a, b = rnd_fp_arr(21, n), rnd_fp_arr(22, n)
+    edge = np.stack([o.to_limbs(v) for v in (0, 1, m.P - 1, m.P - 2, 2, (m.P + 1) // 2)])
+    a[: len(edge)] = edge
+    b[: len(edge)] = edge[::-1]
+    ai, bi = o.arr_to_ints(a), o.arr_to_ints(b)
+    want = {"mul": [x * y % m.P for x, y in zip(ai, bi)], "add": [(x + y) % m.P for x, y in zip(ai, bi)],
+            "sub": [(x - y) % m.P for x, y in zip(ai, bi)], "neg": [(-x) % m.P for x in ai], "square": [x * x % m.P for x in ai],
+            "invert": [pow(x, -1, m.P) if x else 0 for x in ai]}
+    for op, w in want.items():
+        got = eng.fp_op(op, a, None if op in ("neg", "square", "invert") else b, core28=core28)
+        assert o.arr_to_ints(got) == w, op
+    for i in range(0, n, 61):
+        assert np.array_equal(eng.fp_op("sub", a[i:i + 1], b[i:i + 1], core28=core28)[0], o.fp_sub(a[i], b[i]))
+        assert np.array_equal(eng.fp_op("neg", a[i:i + 1], core28=core28)[0], o.fp_neg(a[i]))
+
+
+def _rnd_records(seed, n, nfp):
+    """n records of 72 u64 with nfp random canonical Fp values in front, zeros behind"""
+    out = np.zeros((n, 72), dtype=np.uint64)
+    out[:, :6 * nfp] = rnd_fp_arr(seed, n * nfp).reshape(n, 6 * nfp)
+    return out
+
+
+def test_tower_ops_direct_vs_oracle(keng, ref_kats):
+    """Fp2 / Fp6 / Fp12 primitives through zkp_tower_op_batch (thread family: zkp_field.hpp; cooperative family: the
+    generated step programs) against the oracle: reference src/fp2.rs:171-209, src/fp6.rs:188-288, src/fp12.rs:99-210,
+    the TRUE Frobenius, on seeded operands and on the operands of the reference's fp6 / fp12 test_arithmetic."""
+    n = 40
+    H = lambda s: int(s, 16)
+    a12, b12 = _rnd_records(31, n, 12), _rnd_records(32, n, 12)
+    for j, key in enumerate(("a", "b", "c")):           # src/fp12.rs:413-799 operands (raw integers reduced mod p)
+        a12[j] = np.concatenate([o.to_limbs(H(x) % m.P) for x in ref_kats["fp12_arith"][key]])
+        b12[j] = np.concatenate([o.to_limbs(H(x) % m.P) for x in ref_kats["fp12_arith"][("b", "c", "a")[j]]])
+    a6, b6 = _rnd_records(33, n, 6), _rnd_records(34, n, 6)
+    for j, key in enumerate(("a", "b", "c")):           # src/fp6.rs:561-757 operands
+        a6[j, :36] = np.concatenate([o.to_limbs(H(x) % m.P) for x in ref_kats["fp6_arith"][key]])
+        b6[j, :36] = np.concatenate([o.to_limbs(H(x) % m.P) for x in ref_kats["fp6_arith"][("b", "c", "a")[j]]])
+    a2, b2 = _rnd_records(35, n, 2), _rnd_records(36, n, 2)
+
+    def check(op, a, b, width, fn):
+        got = keng.tower_op(op, a, b)
+        for i in range(n):
+            want = np.zeros(72, dtype=np.uint64)
+            want[:width] = fn(i)
+            assert np.array_equal(got[i], want), (op, i)
+
+    check("fp2_mul", a2, b2, 12, lambda i: o.fp2_mul(a2[i, :12], b2[i, :12]))
+    check("fp2_square", a2, None, 12, lambda i: o.fp2_square(a2[i, :12]))
+    check("fp6_mul", a6, b6, 36, lambda i: o.fp6_mul(a6[i, :36], b6[i, :36]))
+    check("fp6_square", a6, None, 36, lambda i: o.fp6_square(a6[i, :36]))
+    check("fp6_frobenius", a6, None, 36, lambda i: o.fp6_frobenius_map(a6[i, :36]))
+    check("fp12_mul", a12, b12, 72, lambda i: o.fp12_mul(a12[i], b12[i]))
+    check("fp12_square", a12, None, 72, lambda i: o.fp12_square(a12[i]))
+    check("fp12_mul_by_014", a12, b6, 72, lambda i: o.fp12_mul_by_014(a12[i], b6[i, :12], b6[i, 12:24], b6[i, 24:36]))
+    check("fp12_frobenius", a12, None, 72, lambda i: o.fp12_frobenius_map(a12[i]))
+    check("fp12_conjugate", a12, None, 72, lambda i: o.fp12_conjugate(a12[i]))
+    # cyclotomic subgroup elements: Gt values of random pairs (and the identity)
+    from zkvm_pairings_amd import synthetic
+    g1, g2, _, _ = synthetic.random_pairs(keng, n, seed=4711)
+    gt = o.pairing_batch(g1, g2, nthreads=NTHREADS)
+    gt[0] = keng.gt_identity()
+    check("fp12_cyclotomic_square", gt, None, 72, lambda i: o.fp12_cyclotomic_square(gt[i]))
+    for rep in (1, 2, 16, 63, 64):
+        got = keng.tower_op("fp12_cyclotomic_pow2k", gt, None, repeat=rep)
+        for i in (0, 1, 2, n - 1):
+            w = gt[i]
+            for _ in range(rep):
+                w = o.fp12_cyclotomic_square(w)
+            assert np.array_equal(got[i], w), (rep, i)
+    assert keng.tower_op("fp12_mul", a12[:0], b12[:0]).shape == (0, 72)
 
 
 def test_scalar_mul_golden_and_oracle(keng, model_vectors):

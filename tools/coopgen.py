@@ -307,6 +307,13 @@ def encode_form(f):
 
 
 # ------------------------------------------------------------------------------------------ program builder
+class Seg:
+    """one step program of a multi-kernel plan (what encode() and the emulator need of a Builder)"""
+
+    def __init__(self, steps, peak):
+        self.steps, self.peak = steps, peak
+
+
 class Builder:
     K_REDUCED = 1.05      # |value| / p after a Montgomery reduction of a budget-respecting accumulation
     K_VRED = 0.51         # after the value renormalisation
@@ -320,6 +327,7 @@ class Builder:
         self.peak = 0
         self.K = {}           # static worst-case |value|/p per group-local slot
         self.L = {}           # limb bound of a slot in units of 2^27 (1 unless it holds a stored sum of two values)
+        self.plan = []        # finished segments of a multi-kernel program: ("prog", Seg) / kernel steps (see cut)
 
     def kof(self, slot):
         return 1.0 if slot >= CONST_BASE else self.K.get(slot, self.K_INPUT)
@@ -341,6 +349,18 @@ class Builder:
 
     def alloc12(self):
         return V12(self.alloc(12))
+
+    def cut(self, kernel_steps):
+        """end the current step program (every LDS slot must be free: nothing survives between launches but the
+        per-check state buffer), queue the given non-interpreter kernel steps, start a new step program"""
+        assert len(self.free) == NSLOT, "values still LDS-resident at a program boundary"
+        self.plan.append(("prog", Seg(self.steps, self.peak)))
+        self.plan += list(kernel_steps)
+        self.steps, self.peak, self.K, self.L = [], 0, {}, {}
+
+    def finish_plan(self):
+        self.plan.append(("prog", Seg(self.steps, self.peak)))
+        return self.plan
 
     # ---- raw steps
     def lin(self, lanes):
@@ -739,7 +759,12 @@ ST_NINV = 21    # 1 : n^-1                      (its output)
 ST_TI = 22      # 6 : t^-1 (Fp6), parked while conj(f)^2 is formed
 ST_SPILL = 28   # 8 x 12 spill areas used by the hard part
 ST_G = ST_SPILL  # 12: Miller value of a later group of pairs (k > 4), multiplied into ST_F before the final exponentiation
-ST_SIZE = ST_SPILL + 8 * 12
+ST_SNAP = ST_SPILL + 8 * 12   # 6 x 12: snapshots of a compressed squaring run (k_ksq writes z2..z5, k_kdec_b adds z0, z1)
+ST_KN = ST_SNAP + 6 * 12      # 6 : |D|^2 of the six decompressions (input planes of the batched inversion)
+ST_KNINV = ST_KN + 6          # 6 : their inverses
+ST_SIZE = ST_KNINV + 6
+# plan step kinds of a multi-kernel program (the final exponentiation's phase C)
+PLAN_PROG, PLAN_KSQ, PLAN_KDEC_A, PLAN_INV, PLAN_KDEC_B = 0, 1, 2, 3, 4
 
 
 def prog_fexp_a(from_wire):
@@ -780,9 +805,10 @@ def prog_fexp_a(from_wire):
 
 
 def sqr_run(b, v, n):
-    """n cyclotomic squarings in place.  The run keeps 12 companion slots (x0 + x1, x0 - x1 of every Fp2 coefficient,
-    written by each squaring's epilogue): after the first squaring every operand form of the step is a stored value
-    or a shifted one, so the product loop fetches no second operands."""
+    """n cyclotomic squarings in place on the interpreter (timing programs only; the x-power chains run compressed
+    squarings, cyc_exp).  The run keeps 12 companion slots (x0 + x1, x0 - x1 of every Fp2 coefficient, written by
+    each squaring's epilogue): after the first squaring every operand form of the step is a stored value or a
+    shifted one, so the product loop fetches no second operands."""
     if n <= 0:
         return v
     sd = b.alloc(12)
@@ -797,30 +823,36 @@ def sqr_run(b, v, n):
     return V12(v.slots)
 
 
+X_BITS = [i for i in range(64) if (M.BLS_X >> i) & 1]       # 16, 48, 57, 60, 62, 63
+KSQ_NSQ = X_BITS[-1]                                         # squarings of one x-power run
+KSQ_MASK = sum(1 << (e - 1) for e in X_BITS)                 # snapshot after squaring number e (loop index e - 1)
+
+
 def cyc_exp(b, a, park):
-    """-> (conj(a^|x|) in freshly allocated slots, spill handle of a).  a (cyclotomic subgroup) is parked in state area
-    `park` for the whole chain - the squaring runs need its slots for their companions - and filled for the
-    multiplications at the set bits of |x| (MSB first)."""
-    bits = bin(M.BLS_X)[2:]
-    r = b.copy12(b.alloc(12), a)   # leading one
+    """-> (conj(a^|x|) in freshly allocated slots, spill handle of a).  a (cyclotomic subgroup) goes to state area `park`,
+    ONE compressed squaring run (k_ksq) squares it 63 times and keeps the six powers a^(2^e), e the set bits of |x|, the
+    decompression kernels complete them, and the step program multiplies them: a^|x| = prod_e a^(2^e)."""
+    if any(s != 1 for s in a.signs):
+        a = b.copy12(a, a)            # the kernels read raw records: a conjugated view must be materialised
+    assert max(b.kof(s) for s in a.slots) <= Builder.K_INPUT
     ha = b.spill(a, park)
-    run = 0
-    for bit in bits[1:]:
-        run += 1
-        if bit == "1":
-            r = sqr_run(b, r, run)
-            run = 0
-            av = b.fill(ha)
-            r = b.fp12_mul(r, r, av)
-            b.release(av.slots)
-    r = sqr_run(b, r, run)
+    n = len(X_BITS)
+    b.cut([(PLAN_KSQ, park, ST_SNAP, KSQ_NSQ, KSQ_MASK), (PLAN_KDEC_A, ST_SNAP, n, ST_KN), (PLAN_INV, ST_KN, ST_KNINV, n),
+           (PLAN_KDEC_B, ST_SNAP, n, ST_KNINV)])
+    snap = lambda k: (ST_SNAP + 12 * k, [1] * 12, Builder.K_REDUCED)
+    r = b.fill(snap(n - 1))
+    for k in range(n - 2, -1, -1):
+        s = b.fill(snap(k))
+        r = b.fp12_mul(r, r, s)
+        b.release(s.slots)
     return r.conj(), ha
 
 
 def prog_fexp_c(to_wire=True):
     """second half: finish the inversion, easy part, hard part (x-chain), output Gt.  At most TWO Fp12
     values are LDS-resident at any time (24 slots => 16 waves per CU); everything else is parked in the
-    per-check state buffer (a spill or fill moves 768 B per check)."""
+    per-check state buffer (a spill or fill moves 768 B per check).  Returns a PLAN (Builder.cut): the step program is
+    cut at every x-power chain, whose 63 squarings run as one compressed squaring kernel (cyc_exp)."""
     b = Builder()
     st = b.alloc(9)
     b.gload(K_STATE, [(st[i], ST_C + i) for i in range(6)] + [(st[6 + i], ST_NC + i) for i in range(2)] + [(st[8], ST_NINV)])
@@ -903,7 +935,23 @@ def prog_fexp_c(to_wire=True):
     t3 = b.fp12_mul(t3, t3, t1)
     b.release(t1.slots)
     finish_output(b, t3, to_wire, ST_F, check_identity=True)
-    return b
+    return b.finish_plan()
+
+
+_FEXP_C_PLAN = None
+
+
+def fexp_c_plan():
+    """the final exponentiation's phase C as a plan: [("prog", Seg) | (PLAN_KSQ, elem_in, elem_snap, nsq, mask) |
+    (PLAN_KDEC_A, elem_snap, count, elem_n) | (PLAN_INV, elem_n, elem_ninv, count) | (PLAN_KDEC_B, elem_snap, count, elem_ninv)]"""
+    global _FEXP_C_PLAN
+    if _FEXP_C_PLAN is None:
+        _FEXP_C_PLAN = prog_fexp_c(True)
+    return _FEXP_C_PLAN
+
+
+def fexp_c_segments():
+    return [st[1] for st in fexp_c_plan() if st[0] == "prog"]
 
 
 # ------------------------------------------------------------------------------------------ emulator (bit-accurate)
@@ -1127,6 +1175,215 @@ class Emu:
         return self
 
 
+# ---- limb-exact models of the non-interpreter kernels of a plan (zkp_coop.hip k_ksq, k_kdec_a, k_kdec_b) -------------
+def mont_mul(pairs):
+    """reduce(sum of limb-vector products): zkp28::acc_mul + acc_reduce == mont_mul_ps (same columns, same m_i)"""
+    col = [0] * (2 * NL - 1)
+    for a, b in pairs:
+        assert all(abs(x) < (1 << 31) for x in a) and all(abs(x) < (1 << 31) for x in b)
+        for i in range(NL):
+            if a[i]:
+                for j in range(NL):
+                    col[i + j] += a[i] * b[j]
+    assert max(abs(c) for c in col) < (1 << 62), "column overflow in accumulation"
+    return acc_reduce(col)
+
+
+def sq_combine(t, x, neg):
+    """zkp_coop.hip sq_combine: 3 t + 2 sgn x - q p as one exact carry chain"""
+    sx = [-v for v in x] if neg else list(x)
+    top = 3 * t[NL - 1] + 2 * sx[NL - 1]
+    assert abs(top) < (1 << 31)
+    q = ((top >> VRED_SHIFT_IN) * VRED_C + (1 << (VRED_SHIFT_OUT - 1))) >> VRED_SHIFT_OUT
+    assert abs(q) <= 14
+    out, v = [], 0
+    for i in range(NL):
+        assert abs(t[i]) < (1 << 31) and abs(sx[i]) < (1 << 31)
+        v += 3 * t[i] + 2 * sx[i] - q * P_BAL[i]
+        assert abs(v) < (1 << 62)
+        if i < NL - 1:
+            u = v + (1 << (W - 1))
+            out.append((u & ((1 << W) - 1)) - (1 << (W - 1)))
+            v = u >> W
+        else:
+            assert abs(v) < (1 << 31)
+            out.append(v)
+    assert abs(limbs_value(out)) < 0.51 * P
+    return out
+
+
+KS_TU, KS_TV = (3, 1), (2, 5)       # tower positions of (u, v) = (z2, z3) for lanes 0, 1 and (z4, z5) for lanes 2, 3
+
+
+def emu_ksq(state, elem_in, elem_snap, nsq, mask):
+    """k_ksq on one check: four lanes, lane r computes A23, B23, A45, B45; state is updated in place"""
+    vadd = lambda a, b: [x + y for x, y in zip(a, b)]
+    vsub = lambda a, b: [x - y for x, y in zip(a, b)]
+
+    def form(r, mine, other):
+        (mr, mi), (o_r, oi) = mine, other
+        if r & 1:
+            return [list(mr), list(mi), list(o_r), list(oi)]
+        xr, xi = vadd(mr, o_r), vadd(mi, oi)
+        mine_is_v = r in (0, 3)
+        return [xr, xi, vsub(xr, mi if mine_is_v else oi), vadd(xi, mr if mine_is_v else o_r)]
+
+    pairv = []
+    for pr in range(2):
+        u = (state[elem_in + 2 * KS_TU[pr]], state[elem_in + 2 * KS_TU[pr] + 1])
+        v = (state[elem_in + 2 * KS_TV[pr]], state[elem_in + 2 * KS_TV[pr] + 1])
+        pairv.append((u, v))
+    mine = [pairv[0][1], pairv[0][0], pairv[1][0], pairv[1][1]]
+    other = [pairv[0][0], pairv[0][1], pairv[1][1], pairv[1][0]]
+    snap = elem_snap
+    for it in range(nsq):
+        prod = []
+        for r in range(4):
+            xr, xi, yr, yi = form(r, mine[r], other[r])
+            sim = mont_mul([(xr, yi), (xi, yr)])
+            nxi = [-x for x in xi]
+            sre = mont_mul([(xr, yr), (nxi, yi)])
+            prod.append((sre, sim))
+        new = []
+        for r in range(4):
+            ao, bo = prod[(r & 2) ^ 2], prod[((r & 2) ^ 2) | 1]
+            if not (r & 1):
+                tr = [a - 2 * b + c for a, b, c in zip(ao[0], bo[0], bo[1])]
+                ti = [a - b - 2 * c for a, b, c in zip(ao[1], bo[0], bo[1])]
+            elif r == 1:
+                tr = [2 * (b - c) for b, c in zip(bo[0], bo[1])]
+                ti = [2 * (b + c) for b, c in zip(bo[0], bo[1])]
+            else:
+                tr, ti = [2 * b for b in bo[0]], [2 * c for c in bo[1]]
+            neg = not (r & 1)
+            new.append((sq_combine(tr, mine[r][0], neg), sq_combine(ti, mine[r][1], neg)))
+        mine = new
+        other = [new[r ^ 1] for r in range(4)]
+        if (mask >> it) & 1:
+            for r in (0, 2):
+                pr = r >> 1
+                tm, to = (KS_TV[pr], KS_TU[pr]) if r == 0 else (KS_TU[pr], KS_TV[pr])
+                state[snap + 2 * tm], state[snap + 2 * tm + 1] = list(mine[r][0]), list(mine[r][1])
+                state[snap + 2 * to], state[snap + 2 * to + 1] = list(other[r][0]), list(other[r][1])
+            snap += 12
+    return state
+
+
+def _c_lin(a, b, sb):
+    return weak_norm([x + sb * y for x, y in zip(a, b)])
+
+
+def c2_add(a, b):
+    return (_c_lin(a[0], b[0], 1), _c_lin(a[1], b[1], 1))
+
+
+def c2_sub(a, b):
+    return (_c_lin(a[0], b[0], -1), _c_lin(a[1], b[1], -1))
+
+
+def c2_dbl(a):
+    return c2_add(a, a)
+
+
+def c2_sqr(a):
+    """zkp_coop.hip c_sqr on a lane pair: (a0 + a1)(a0 - a1), (2 a0) a1"""
+    s = [x + y for x, y in zip(a[0], a[1])]
+    d = [x - y for x, y in zip(a[0], a[1])]
+    return (mont_mul([(s, d)]), mont_mul([([2 * x for x in a[0]], a[1])]))
+
+
+def c2_mul(a, b):
+    """zkp_coop.hip c_mul_q on a lane pair"""
+    return (mont_mul([(a[0], b[0]), ([-x for x in a[1]], b[1])]), mont_mul([(a[0], b[1]), (a[1], b[0])]))
+
+
+def c2_xi(a):
+    """xi a formed the way the kernels do: lane 0 mine - other, lane 1 other + mine"""
+    return (_c_lin(a[0], a[1], -1), _c_lin(a[0], a[1], 1))
+
+
+def c2_is_zero(a):
+    return limbs_value(a[0]) % P == 0 and limbs_value(a[1]) % P == 0
+
+
+def _snap_fp2(state, base, pos):
+    return (state[base + 2 * pos], state[base + 2 * pos + 1])
+
+
+def emu_kdec_a(state, elem_snap, count, elem_n):
+    for sn in range(count):
+        base = elem_snap + 12 * sn
+        z2, z3, z4, z5 = (_snap_fp2(state, base, pos) for pos in (3, 2, 1, 5))
+        z2_zero = c2_is_zero(z2)
+        na = c2_xi(c2_sqr(z5))
+        s4 = c2_sqr(z4)
+        na = c2_sub(c2_add(na, c2_add(c2_dbl(s4), s4)), c2_dbl(z3))
+        nb = c2_dbl(c2_mul(z4, z5))
+        N, D = (nb, z3) if z2_zero else (na, z2)
+        n = mont_mul([(D[0], D[0]), (D[1], D[1])])
+        if not z2_zero:
+            n = _c_lin(n, n, 1)
+            n = _c_lin(n, n, 1)
+        state[base + 8], state[base + 9] = N
+        state[base + 0], state[base + 1] = D
+        state[elem_n + sn] = n
+    return state
+
+
+def emu_inv(state, elem_n, elem_ninv, count):
+    """value-exact stand-in for k_batch_inv (its limbs depend on the batching); zero gives zero"""
+    for j in range(count):
+        v = from_mont(state[elem_n + j])
+        state[elem_ninv + j] = mont(M.fp_inv(v)) if v else [0] * NL
+    return state
+
+
+def emu_kdec_b(state, elem_snap, count, elem_ninv):
+    one = (const_limbs("ONE", 1), [0] * NL)
+    for sn in range(count):
+        base = elem_snap + 12 * sn
+        N = (state[base + 8], state[base + 9])
+        D = (state[base + 0], state[base + 1])
+        ninv = state[elem_ninv + sn]
+        dinv = (mont_mul([(D[0], ninv)]), mont_mul([([-x for x in D[1]], ninv)]))
+        z1 = c2_mul(N, dinv)
+        z2, z3, z4, z5 = (_snap_fp2(state, base, pos) for pos in (3, 2, 1, 5))
+        t = c2_add(c2_dbl(c2_sqr(z1)), c2_mul(z2, z5))
+        m34 = c2_mul(z3, z4)
+        t = c2_sub(t, c2_add(c2_dbl(m34), m34))
+        t = (vred(t[0]), vred(t[1]))
+        xt = c2_xi(t)
+        z0 = (vred(_c_lin(xt[0], one[0], 1)), vred(xt[1]))
+        state[base + 0], state[base + 1] = z0
+        state[base + 8], state[base + 9] = z1
+    return state
+
+
+def run_plan(plan, state, wire_in=None):
+    """emulate a multi-kernel plan on one check; returns the Emu of the last step program (state, wire_out, ...)"""
+    state = dict(state)
+    em = None
+    stats = {"max_col": 0, "mulacc_steps": 0}
+    for st in plan:
+        if st[0] == "prog":
+            em = Emu(state=state, wire_in=wire_in).run(st[1].steps)
+            state = em.state
+            stats["max_col"] = max(stats["max_col"], em.max_col)
+            stats["mulacc_steps"] += em.counts["mulacc_steps"]
+        elif st[0] == PLAN_KSQ:
+            emu_ksq(state, *st[1:])
+        elif st[0] == PLAN_KDEC_A:
+            emu_kdec_a(state, *st[1:])
+        elif st[0] == PLAN_INV:
+            emu_inv(state, *st[1:])
+        elif st[0] == PLAN_KDEC_B:
+            emu_kdec_b(state, *st[1:])
+        else:
+            raise ValueError(st[0])
+    em.plan_stats = stats
+    return em
+
+
 def model_lines(pairs):
     """line stream for a check: list over the 68 steps of [per pair (c2, c1*xP, c0*yP)]; pairs with an
     infinity get the neutral line (1, 0, 0)."""
@@ -1234,6 +1491,73 @@ def encode(builder):
     return hdr, tbl
 
 
+# ---- direct hooks for the tower primitives (zkp_tower_op_batch): wire records in, wire record out -------------------------
+TOWER_OPS = ("fp2_mul", "fp2_sqr", "fp6_mul", "fp6_sqr", "fp12_mul", "fp12_sqr", "fp12_014", "fp12_frob", "fp12_conj", "cyc_sqr")
+
+
+def prog_tower(op):
+    """one tower operation on wire records (72 u64; smaller tower elements occupy the leading coefficients, the rest
+    of the result is zero): a = record of the check, b = record of check + chk_off.  Reference formulas: Fp2 mul / square
+    src/fp2.rs:171-209, Fp6 mul / square src/fp6.rs:188-288, Fp12 mul / square / mul_by_014 / conjugate src/fp12.rs:99-210,
+    TRUE Frobenius (src/fp12.rs:143-170 is built on the wrong Fp6 map), Granger-Scott cyclotomic squaring."""
+    b = Builder()
+    a = load_input(b, True)
+    bb = load_input(b, True, wire_kind=K_WIRE2) if op in ("fp2_mul", "fp6_mul", "fp12_mul", "fp12_014") else None
+    t = bb.slots if bb else b.alloc(12)          # 24 slots in all: results go to a's slots, the wire conversion to t
+
+    def out_wire(v):
+        raw1 = Lin.of(CONST_SLOT["RAW_ONE"])
+        b.mulacc([{"dst": t[i], "bil": Bil([(v.lin(i), raw1, 1)])} for i in range(12)])
+        b.gstore(K_WIRE, [(t[i], i) for i in range(12)])
+        return b
+
+    if op == "fp12_conj":
+        return out_wire(a.conj())
+    if op == "fp12_frob":
+        r = b.frobenius(t, a, 1)
+        t = a.slots
+    elif op == "fp12_mul":
+        r = b.fp12_mul(a, a, bb)
+    elif op == "fp12_sqr":
+        r = b.fp12_sqr(t, a)
+        t = a.slots
+    elif op == "fp12_014":
+        r = b.fp12_mul_by_014(a, a, bb.fp2(0), bb.fp2(1), bb.fp2(2))
+    elif op == "cyc_sqr":
+        r = b.cyclotomic_sqr(t, a)
+        t = a.slots
+    else:
+        if op == "fp2_mul":
+            parts = list(b2_mul(a.fp2(0), bb.fp2(0)))
+        elif op == "fp2_sqr":
+            parts = list(b2_sqr(a.fp2(0)))
+        else:
+            x = a.fp6(0)
+            parts = [c for pr in b6_mul(x, bb.fp6(0) if op == "fp6_mul" else x) for c in pr]
+        d = a.slots
+        b.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(parts)])
+        b.lin([(d[i], Lin.of(ZERO)) for i in range(len(parts), 12)])
+        r = V12(d)
+    return out_wire(r)
+
+
+def prog_tower_to_state():
+    """wire record -> Montgomery limbs in state elements 0..11 (input of a compressed squaring run)"""
+    b = Builder()
+    f = load_input(b, True)
+    b.gstore(K_STATE, [(f.slots[i], i) for i in range(12)])
+    return b
+
+
+def prog_tower_from_snap():
+    """first snapshot area of the state buffer -> canonical wire record"""
+    b = Builder()
+    f = V12(b.alloc(12))
+    b.gload(K_STATE, [(f.slots[i], ST_SNAP + i) for i in range(12)], kbound=Builder.K_REDUCED)
+    finish_output(b, f, True, 0)
+    return b
+
+
 def prog_timing(T, epi, nloop=400, lin=False):
     """synthetic timing program (not a meaningful computation): LOOP nloop { MULACC with T two-term products
     per lane (+ epilogue) } or { LIN with 3 terms }"""
@@ -1319,7 +1643,6 @@ PROGRAMS = {
     "f12mul_wire": lambda: prog_f12mul(True),
     "fexp_a_state": lambda: prog_fexp_a(False),
     "fexp_a_wire": lambda: prog_fexp_a(True),
-    "fexp_c": lambda: prog_fexp_c(True),
     "time_t1": lambda: prog_timing(1, False),
     "time_t3": lambda: prog_timing(3, False),
     "time_t3e": lambda: prog_timing(3, True),
@@ -1330,6 +1653,14 @@ PROGRAMS = {
     "time_cycsd": lambda: prog_timing_cyc(True),
     "time_fill": prog_timing_fill,
 }
+
+
+for _op in TOWER_OPS:
+    PROGRAMS["tw_" + _op] = (lambda op=_op: prog_tower(op))
+PROGRAMS["tw_to_state"] = prog_tower_to_state
+PROGRAMS["tw_from_snap"] = prog_tower_from_snap
+for _i in range(len(fexp_c_segments())):
+    PROGRAMS["fexp_c%d" % _i] = (lambda i=_i: fexp_c_segments()[i])
 
 
 def lds_config(peak, nconst):
@@ -1347,6 +1678,7 @@ def write_inc(path):
              "#define ZKP_COOP_NCONST %d" % N_CONST, "#define ZKP_COOP_WIDE_NSLOT %d" % LDS_WIDE_SLOTS, "#define ZKP_COOP_WIDE_NCONST %d" % LDS_WIDE_CONSTS,
              "#define ZKP_COOP_ST_SIZE %d" % ST_SIZE,
              "#define ZKP_COOP_ST_G %d" % ST_G, "#define ZKP_COOP_ST_N %d" % ST_N, "#define ZKP_COOP_ST_NINV %d" % ST_NINV,
+             "#define ZKP_COOP_ST_SNAP %d" % ST_SNAP, "#define ZKP_COOP_ST_KN %d" % ST_KN, "#define ZKP_COOP_ST_KNINV %d" % ST_KNINV,
              "#define ZKP_COOP_NLINES %d" % n_line_steps(),
              "#define ZKP_COOP_VRED_C %d" % VRED_C, "#define ZKP_COOP_VRED_SHIFT_IN %d" % VRED_SHIFT_IN,
              "#define ZKP_COOP_VRED_SHIFT_OUT %d" % VRED_SHIFT_OUT,
@@ -1384,6 +1716,23 @@ def write_inc(path):
     for n, nh, nt, peak, nconst, wide in meta:
         lines.append("  {ZKP_PROG_%s_HDR, %d, ZKP_PROG_%s_TBL, %d, %d, %d, %d}," % (n.upper(), nh, n.upper(), max(1, nt), peak, nconst, wide))
     lines.append("};")
+    # phase C of the final exponentiation: step programs alternating with the compressed squaring runs and the decompression
+    lines.append("enum { ZKP_PLAN_PROG = %d, ZKP_PLAN_KSQ = %d, ZKP_PLAN_KDEC_A = %d, ZKP_PLAN_INV = %d, ZKP_PLAN_KDEC_B = %d };"
+                 % (PLAN_PROG, PLAN_KSQ, PLAN_KDEC_A, PLAN_INV, PLAN_KDEC_B))
+    lines.append("// PROG: a = program; KSQ: a = input element, b = first snapshot element, c = squarings, mask = snapshot bits;")
+    lines.append("// KDEC_A: a = snapshots, b = count, c = |D|^2 planes; INV: a = input planes, b = output planes, c = count; KDEC_B: a, b, c = inverse planes")
+    lines.append("struct ZkpPlanStep { uint32_t kind, a, b, c; uint64_t mask; };")
+    rows, seg = [], 0
+    for st in fexp_c_plan():
+        if st[0] == "prog":
+            rows.append("{ZKP_PLAN_PROG, ZKP_PROG_FEXP_C%d, 0, 0, 0}" % seg)
+            seg += 1
+        elif st[0] == PLAN_KSQ:
+            rows.append("{ZKP_PLAN_KSQ, %d, %d, %d, 0x%xull}" % st[1:])
+        else:
+            rows.append("{%d, %d, %d, %d, 0}" % st)
+    lines.append("#define ZKP_FEXP_C_PLAN_LEN %d" % len(rows))
+    lines.append("static const ZkpPlanStep ZKP_FEXP_C_PLAN[ZKP_FEXP_C_PLAN_LEN] = {" + ", ".join(rows) + "};")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
     return meta

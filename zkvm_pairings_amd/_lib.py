@@ -42,6 +42,7 @@ SIGNATURES = {
     "zkp_g1_encode_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "zkp_g2_encode_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp]),
     "zkp_fp_op_batch": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "zkp_tower_op_batch": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, ctypes.c_uint32, c_vp]),
     "zkp_pairing_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp]),
     "zkp_multi_miller_loop_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, c_vp]),
     "zkp_final_exponentiation_batch_dev": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp]),
@@ -54,6 +55,9 @@ SIGNATURES = {
     "zkp_g2_is_valid_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp]),
     "zkp_g1_mul_batch_dev": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp, c_vp, c_vp]),
     "zkp_g2_mul_batch_dev": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "zkp_take_validation_status_dev": (c_int, [c_vp, c_vp, ctypes.POINTER(c_int)]),
+    "zkp_pairing_check_batch_multi": (c_int, [ctypes.POINTER(c_vp), c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, ctypes.POINTER(c_int)]),
+    "zkp_pairing_batch_multi": (c_int, [ctypes.POINTER(c_vp), c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.POINTER(c_int)]),
     "zkp_time_coop_step": (c_int, [c_vp, c_int, c_sz, ctypes.POINTER(ctypes.c_float)]),
     "zkp_time_pairing_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_int, ctypes.POINTER(ctypes.c_float)]),
 }

@@ -368,6 +368,175 @@ __device__ __forceinline__ void rec_load(Fp28& x, const int4* src) {
     x.l[8] = v2.x; x.l[9] = v2.y; x.l[10] = v2.z; x.l[11] = v2.w; x.l[12] = v3.x; x.l[13] = v3.y;
 }
 
+// =============================================================================== compressed squaring runs: four lanes per check
+// The hard part of the final exponentiation is five exponentiations by |x| of values in the cyclotomic subgroup: 63
+// squarings each.  In the interpreter a squaring costs 36 product blocks + 12 reductions on twelve lanes (Granger-Scott,
+// every output coefficient recomputes the Fp2 squares it shares with its neighbour).  Karabina's compressed form
+// (ePrint 2010/542) keeps four of the six Fp2 coefficients, z2..z5 of
+//     g = (z0 + z1 s) + (z2 + z3 s) w + (z4 + z5 s) w^2,   s = w^3, s^2 = xi
+// (tower positions: z0 c0.c0, z4 c0.c1, z3 c0.c2, z2 c1.c0, z1 c1.c1, z5 c1.c2), and the Granger-Scott recurrences of
+// those four need only themselves:
+//     z2' = 6 xi B45 + 2 z2          z3' = 3 (A45 - (1 + xi) B45) - 2 z3        A45 = (z4 + z5)(z4 + xi z5), B45 = z4 z5
+//     z4' = 3 (A23 - (1 + xi) B23) - 2 z4          z5' = 6 B23 + 2 z5           A23 = (z2 + z3)(z2 + xi z3), B23 = z2 z3
+// FOUR Fp2 products per squaring.  k_ksq gives each to one lane (4 product blocks + 2 reductions per lane, four lanes per
+// check, SIXTEEN checks per wavefront, no idle lane), operands in registers, the products exchanged inside the lane quad
+// with DPP (no LDS traffic but the parked copy of a lane's own coefficient, no step tables).  An exponentiation by |x| is
+// ONE run of 63 squarings that stores a snapshot of (z2..z5) after 16, 48, 57, 60, 62 and 63 squarings (the set bits
+// of |x|); k_kdec_a / k_batch_inv / k_kdec_b recover z0, z1 of the six snapshots (one shared batched inversion), and the
+// step program multiplies them.  tools/coopgen.py emu_ksq / emu_kdec are the limb-exact models of these kernels.
+constexpr int KS_CHECKS = 16;
+
+__device__ __forceinline__ void park_st(int4* xch, int lane, const int32_t* re, const int32_t* im) {
+    xch[0 * 64 + lane] = make_int4(re[0], re[1], re[2], re[3]);
+    xch[1 * 64 + lane] = make_int4(re[4], re[5], re[6], re[7]);
+    xch[2 * 64 + lane] = make_int4(re[8], re[9], re[10], re[11]);
+    xch[3 * 64 + lane] = make_int4(re[12], re[13], im[12], im[13]);
+    xch[4 * 64 + lane] = make_int4(im[0], im[1], im[2], im[3]);
+    xch[5 * 64 + lane] = make_int4(im[4], im[5], im[6], im[7]);
+    xch[6 * 64 + lane] = make_int4(im[8], im[9], im[10], im[11]);
+}
+__device__ __forceinline__ void park_ld(int32_t* re, int32_t* im, const int4* xch, int lane) {
+    const int4 r0 = xch[0 * 64 + lane], r1 = xch[1 * 64 + lane], r2 = xch[2 * 64 + lane], r3 = xch[3 * 64 + lane];
+    const int4 i0 = xch[4 * 64 + lane], i1 = xch[5 * 64 + lane], i2 = xch[6 * 64 + lane];
+    re[0] = r0.x; re[1] = r0.y; re[2] = r0.z; re[3] = r0.w; re[4] = r1.x; re[5] = r1.y; re[6] = r1.z; re[7] = r1.w;
+    re[8] = r2.x; re[9] = r2.y; re[10] = r2.z; re[11] = r2.w; re[12] = r3.x; re[13] = r3.y; im[12] = r3.z; im[13] = r3.w;
+    im[0] = i0.x; im[1] = i0.y; im[2] = i0.z; im[3] = i0.w; im[4] = i1.x; im[5] = i1.y; im[6] = i1.z; im[7] = i1.w;
+    im[8] = i2.x; im[9] = i2.y; im[10] = i2.z; im[11] = i2.w;
+}
+// out = 3 t + 2 sgn x - q p (sgn = -1 where neg is all ones) with q = round(value / p) taken from the top limbs, as ONE
+// exact carry chain (balanced limbs, the top limb keeps the rest); |result| < 0.51 p
+__device__ __forceinline__ void sq_combine(int32_t* out, const int32_t* t, const int32_t* x, int32_t neg) {
+    int32_t sx[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) sx[i] = (x[i] ^ neg) - neg;
+    const int32_t top = 3 * t[NL - 1] + 2 * sx[NL - 1];
+    const int32_t q = ((top >> ZKP_COOP_VRED_SHIFT_IN) * ZKP_COOP_VRED_C + (1 << (ZKP_COOP_VRED_SHIFT_OUT - 1))) >> ZKP_COOP_VRED_SHIFT_OUT;
+    int64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        v += (int64_t)t[i] * 3;
+        v += (int64_t)sx[i] * 2;
+        v -= (int64_t)q * (int64_t)K_PBAL[i];
+        if (i < NL - 1) {
+            const int64_t u = v + (1ll << (W - 1));
+            out[i] = (int32_t)((uint32_t)u & (uint32_t)MASK) - (1 << (W - 1));
+            v = u >> W;
+        } else {
+            out[i] = (int32_t)v;
+        }
+    }
+}
+#define ZKP_QUAD(x, ctrl) __builtin_amdgcn_update_dpp(0, (x), (ctrl), 0xf, 0xf, false)
+
+#ifndef ZKP_KSQ_WAVES
+#define ZKP_KSQ_WAVES 4
+#endif
+// nsq compressed squarings of the Fp12 value in state elements [elem_in, elem_in + 12) (only z2..z5 are read); after
+// squaring number it + 1 where bit it of snap_mask is set, (z2..z5) go to the next snapshot area: 12 elements each from
+// elem_snap on, laid out like an Fp12 value whose z0, z1 positions are left for k_kdec_b to fill.
+__global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_in, uint32_t elem_snap,
+                                                           uint32_t nsq, uint64_t snap_mask) {
+    __shared__ int4 parked[7 * 64];
+    const int lane = threadIdx.x;
+    const int r = lane & 3;                        // 0: A23, 1: B23, 2: A45, 3: B45
+    const bool b_lane = r & 1;
+    const bool mine_is_v = r == 0 || r == 3;       // the lane's own new coefficient: z3' (0), z2' (1), z4' (2), z5' (3)
+    const uint32_t check_raw = blockIdx.x * KS_CHECKS + (lane >> 2);
+    const bool active = check_raw < n_checks;
+    const uint32_t check = active ? check_raw : n_checks - 1;
+    const int tu = (r & 2) ? 1 : 3, tv = (r & 2) ? 5 : 2;   // tower positions of the lane's pair (u, v) = (z4, z5) or (z2, z3)
+    int4* const st = state + (size_t)check * 4;
+    auto rec = [&](uint32_t e) -> int4* { return st + (size_t)e * nc * 4; };
+
+    // X, Y: the two factors of the lane's product.  `mine` is the lane's own coefficient of its pair (u, v) - v on lanes 0
+    // and 3, u on lanes 1 and 2 - and `other` the pair partner's.  B lanes: u v = mine * other.  A lanes: (u + v)(u + xi v).
+    int32_t xr[NL], xi[NL], yr[NL], yi[NL];
+    auto advance = [&](const int32_t* mr, const int32_t* mi, const int32_t* o_r, const int32_t* oi) {
+        park_st(parked, lane, mr, mi);            // the "2 z" term of the lane's next combination
+        if (b_lane) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) { xr[i] = mr[i]; xi[i] = mi[i]; yr[i] = o_r[i]; yi[i] = oi[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                xr[i] = mr[i] + o_r[i];
+                xi[i] = mi[i] + oi[i];
+                yr[i] = xr[i] - (mine_is_v ? mi[i] : oi[i]);      // u + xi v = (u0 + v0 - v1) + (u1 + v0 + v1) u
+                yi[i] = xi[i] + (mine_is_v ? mr[i] : o_r[i]);
+            }
+        }
+    };
+    {
+        Fp28 u0, u1, v0, v1;
+        rec_load(u0, rec(elem_in + 2 * tu));
+        rec_load(u1, rec(elem_in + 2 * tu + 1));
+        rec_load(v0, rec(elem_in + 2 * tv));
+        rec_load(v1, rec(elem_in + 2 * tv + 1));
+        if (mine_is_v) advance(v0.l, v1.l, u0.l, u1.l); else advance(u0.l, u1.l, v0.l, v1.l);
+    }
+    uint32_t snap = elem_snap;
+#pragma unroll 1
+    for (uint32_t it = 0; it < nsq; it++) {
+        int32_t sre[NL], sim[NL];
+        // X Y = (X0 Y0 - X1 Y1) + (X0 Y1 + X1 Y0) u, one reduction per coefficient
+        mont_mul_ps<true>(sim, xr, yi, xi, yr);
+#pragma unroll
+        for (int i = 0; i < NL; i++) xi[i] = -xi[i];
+        mont_mul_ps<true>(sre, xr, yr, xi, yi);
+        // the other pair's products: A from its even lane, B from its odd lane.  The DPP reads stay outside the lane-role
+        // branches: a DPP read from a lane that the branch has switched off returns nothing.
+        int32_t tr[NL], ti[NL];
+        {
+            int32_t ar[NL], ai[NL], br[NL], bi[NL];
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                ar[i] = ZKP_QUAD(sre[i], 0x0A);   // quad_perm [2,2,0,0]
+                ai[i] = ZKP_QUAD(sim[i], 0x0A);
+                br[i] = ZKP_QUAD(sre[i], 0x5F);   // quad_perm [3,3,1,1]
+                bi[i] = ZKP_QUAD(sim[i], 0x5F);
+            }
+            if (!b_lane) {         // 3 (A - (1 + xi) B) - 2 old,  (1 + xi) = 2 + u
+#pragma unroll
+                for (int i = 0; i < NL; i++) { tr[i] = ar[i] - 2 * br[i] + bi[i]; ti[i] = ai[i] - br[i] - 2 * bi[i]; }
+            } else if (r == 1) {   // 3 xi (2 B) + 2 old
+#pragma unroll
+                for (int i = 0; i < NL; i++) { tr[i] = 2 * (br[i] - bi[i]); ti[i] = 2 * (br[i] + bi[i]); }
+            } else {               // 3 (2 B) + 2 old
+#pragma unroll
+                for (int i = 0; i < NL; i++) { tr[i] = 2 * br[i]; ti[i] = 2 * bi[i]; }
+            }
+        }
+        int32_t or_[NL], oi[NL];
+        park_ld(or_, oi, parked, lane);
+        const int32_t neg = b_lane ? 0 : -1;
+        sq_combine(sre, tr, or_, neg);
+        sq_combine(sim, ti, oi, neg);
+        // the pair partner's new coefficient completes (u', v')
+        int32_t pr[NL], pi[NL];
+#pragma unroll
+        for (int i = 0; i < NL; i++) { pr[i] = ZKP_QUAD(sre[i], 0xB1); pi[i] = ZKP_QUAD(sim[i], 0xB1); }   // quad_perm [1,0,3,2]
+        if ((snap_mask >> it) & 1) {      // wave-uniform
+            if (active && !b_lane) {      // lane 0 holds (v, u) = (mine, partner), lane 2 (u, v)
+                Fp28 o;
+#pragma unroll
+                for (int i = 0; i < NL; i++) o.l[i] = sre[i];
+                rec_store(rec(snap + 2 * (mine_is_v ? tv : tu)), o);
+#pragma unroll
+                for (int i = 0; i < NL; i++) o.l[i] = sim[i];
+                rec_store(rec(snap + 2 * (mine_is_v ? tv : tu) + 1), o);
+#pragma unroll
+                for (int i = 0; i < NL; i++) o.l[i] = pr[i];
+                rec_store(rec(snap + 2 * (mine_is_v ? tu : tv)), o);
+#pragma unroll
+                for (int i = 0; i < NL; i++) o.l[i] = pi[i];
+                rec_store(rec(snap + 2 * (mine_is_v ? tu : tv) + 1), o);
+            }
+            snap += 12;
+        }
+        advance(sre, sim, pr, pi);
+    }
+}
+
 // ---- two lanes per pair: lane parity c selects the Fp2 coefficient a value's lane holds ------------------
 // An Fp2 value is ONE Fp28 per lane (c = 0: real part, c = 1: imaginary part); add/sub/neg/dbl touch
 // only the lane's own coefficient; products fetch the partner's coefficient with a DPP quad swap.
@@ -937,26 +1106,33 @@ __global__ void __launch_bounds__(64, 2) k_g2_mul28(const uint64_t* base, size_t
     }
 }
 
-// state[ST_NINV] = state[ST_N]^-1 for every check.  One lane inverts B checks (i, i + L, i + 2L, ...; L lanes) with
-// Montgomery's simultaneous inversion: exclusive prefix products parked in the ST_NINV records, ONE Fermat inversion
-// (a^(p-2); reference src/fp.rs:307-319) of the total, then two multiplications per check on the way back.
-// A zero element (a non-invertible final_exponentiation input) is replaced by one in the chain and gets 0, as Fermat gives.
-__global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks, uint32_t nc, uint32_t Bf) {
+// out = in^-1 for `count` planes of per-check Fp elements: plane j of the input is state element elem_n + j, of the output
+// elem_ninv + j (n_checks values each, record stride nc).  The final exponentiation's single inversion is
+// (ST_N, ST_NINV, 1), the decompression of the six snapshots of an x-power chain (ST_KN, ST_KNINV, 6).  One lane inverts
+// B of the count * n_checks values (i, i + L, i + 2L, ...; L lanes) with Montgomery's simultaneous inversion: exclusive
+// prefix products parked in the output records, ONE inversion (a^(p-2) in the reference, src/fp.rs:307-319) of the total,
+// then two multiplications per value on the way back.
+// A zero element (a non-invertible final_exponentiation input, the identity's compressed form) is replaced by one in the
+// chain and gets 0, as Fermat gives.
+__global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks, uint32_t nc, uint32_t Bf, uint32_t elem_n, uint32_t elem_ninv,
+                                                  uint32_t count) {
     const uint32_t B = Bf & 0x7fffffffu;
     const bool fermat = Bf >> 31;               // cross-check path (ZKP_COOP_INV_FERMAT=1)
-    const uint32_t L = (n_checks + B - 1) / B;
+    const uint32_t total = n_checks * count;
+    const uint32_t L = (total + B - 1) / B;
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= L) return;
-    int4* N = state + (size_t)ZKP_COOP_ST_N * nc * 4;
-    int4* I = state + (size_t)ZKP_COOP_ST_NINV * nc * 4;
+    auto recno = [&](uint32_t idx) -> size_t { const uint32_t j = idx / n_checks; return ((size_t)j * nc + (idx - j * n_checks)) * 4; };
+    int4* N = state + (size_t)elem_n * nc * 4;
+    int4* I = state + (size_t)elem_ninv * nc * 4;
     Fp28 acc = f_const(K28_ONE);
     uint32_t cnt = 0;
 #pragma unroll 1
-    for (uint32_t idx = i; idx < n_checks && cnt < B; idx += L, cnt++) {
+    for (uint32_t idx = i; idx < total && cnt < B; idx += L, cnt++) {
         Fp28 e;
-        rec_load(e, N + (size_t)idx * 4);
+        rec_load(e, N + recno(idx));
         if (B > 1) {
-            rec_store(I + (size_t)idx * 4, acc);
+            rec_store(I + recno(idx), acc);
             if (f_is_zero(e)) e = f_const(K28_ONE);
             fp28_mul(acc, acc, e);
         } else {
@@ -964,31 +1140,119 @@ __global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks
         }
     }
     Fp28 inv = fermat ? f_inv_fermat(acc) : f_inv(acc);
-    if (B == 1) { rec_store(I + (size_t)i * 4, inv); return; }
+    if (B == 1) { rec_store(I + recno(i), inv); return; }
 #pragma unroll 1
     for (uint32_t j = cnt; j-- > 0;) {
-        const size_t idx = (size_t)i + (size_t)j * L;
+        const size_t at = recno(i + j * L);
         Fp28 e, pre, r;
-        rec_load(e, N + idx * 4);
-        rec_load(pre, I + idx * 4);
+        rec_load(e, N + at);
+        rec_load(pre, I + at);
         if (f_is_zero(e)) {
             f_zero(r);
         } else {
             fp28_mul(r, inv, pre);
             fp28_mul(inv, inv, e);
         }
-        rec_store(I + idx * 4, r);
+        rec_store(I + at, r);
     }
 }
 
-// fp28 multiply on wire operands (test hook for the 28-bit core)
-__global__ void k_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+// ---- decompression of snapshots (z2..z5 known, z0 and z1 to recover; Karabina, ePrint 2010/542 Theorem 3.1 in this
+// tower's coordinates - tools/coopgen.py checks the identities against the big-integer model):
+//     z2 != 0:  z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2)          z2 == 0:  z1 = 2 z4 z5 / z3   (0 / 0 := 0: the identity)
+//     z0 = (2 z1^2 + z2 z5 - 3 z3 z4) xi + 1
+// Two lanes per (snapshot, check) - lane parity = Fp2 coefficient, as in k_prep_lines.  k_kdec_a leaves the numerator N in the
+// snapshot's z1 records, the denominator D (z2 or z3) in its z0 records and n = |D|^2 (x 4 where D = z2) in plane
+// elem_n + snapshot; k_batch_inv inverts the planes; k_kdec_b finishes: 1 / D = conj(D) / |D|^2.
+__global__ void __launch_bounds__(64, 2) k_kdec_a(int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_snap, uint32_t count, uint32_t elem_n) {
+    const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
+    const int c = (int)(tid & 1);
+    uint32_t e = tid >> 1;
+    const bool live = e < n_checks * count;
+    if (!live) e = n_checks * count - 1;
+    const uint32_t sn = e / n_checks, check = e - sn * n_checks;
+    int4* const st = state + (size_t)check * 4;
+    const uint32_t base = elem_snap + 12 * sn;
+    auto rec = [&](uint32_t el) -> int4* { return st + (size_t)el * nc * 4; };
+    F2 f{c};
+    Fp28 z2, z3, z4, z5;
+    rec_load(z2, rec(base + 6 + c));
+    rec_load(z3, rec(base + 4 + c));
+    rec_load(z4, rec(base + 2 + c));
+    rec_load(z5, rec(base + 10 + c));
+    const bool z2_zero = f.is_zero(z2);
+    Fp28 s5 = f.sqr(z5), o;
+    swap_pair(o, s5);
+    Fp28 na = c ? c_add(o, s5) : c_sub(s5, o);                 // xi z5^2
+    Fp28 s4 = f.sqr(z4);
+    na = c_sub(c_add(na, c_add(c_dbl(s4), s4)), c_dbl(z3));
+    Fp28 nb = c_dbl(f.mul(z4, z5));
+    Fp28 N = z2_zero ? nb : na, D = z2_zero ? z3 : z2;
+    swap_pair(o, D);
+    Acc acc;
+    acc_zero(acc);
+    acc_mul(acc, D.l, D.l);
+    acc_mul(acc, o.l, o.l);
+    Fp28 n;
+    acc_reduce(n.l, acc);
+    if (!z2_zero) n = c_dbl(c_dbl(n));
+    if (live) {
+        rec_store(rec(base + 8 + c), N);
+        rec_store(rec(base + c), D);
+        if (c == 0) rec_store(rec(elem_n + sn), n);
+    }
+}
+__global__ void __launch_bounds__(64, 2) k_kdec_b(int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_snap, uint32_t count, uint32_t elem_ninv) {
+    const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
+    const int c = (int)(tid & 1);
+    uint32_t e = tid >> 1;
+    const bool live = e < n_checks * count;
+    if (!live) e = n_checks * count - 1;
+    const uint32_t sn = e / n_checks, check = e - sn * n_checks;
+    int4* const st = state + (size_t)check * 4;
+    const uint32_t base = elem_snap + 12 * sn;
+    auto rec = [&](uint32_t el) -> int4* { return st + (size_t)el * nc * 4; };
+    F2 f{c};
+    Fp28 N, D, ninv;
+    rec_load(N, rec(base + 8 + c));
+    rec_load(D, rec(base + c));
+    rec_load(ninv, rec(elem_ninv + sn));
+    Fp28 dinv = f_mul_v(c ? c_neg(D) : D, ninv);               // conj(D) / |D|^2
+    Fp28 z1 = f.mul(N, dinv);
+    Fp28 z2, z3, z4, z5;
+    rec_load(z2, rec(base + 6 + c));
+    rec_load(z5, rec(base + 10 + c));
+    Fp28 t = c_add(c_dbl(f.sqr(z1)), f.mul(z2, z5));
+    rec_load(z3, rec(base + 4 + c));
+    rec_load(z4, rec(base + 2 + c));
+    Fp28 m34 = f.mul(z3, z4);
+    t = f_vred(c_sub(t, c_add(c_dbl(m34), m34)));
+    Fp28 o;
+    swap_pair(o, t);
+    Fp28 z0 = c ? c_add(o, t) : c_add(c_sub(t, o), f_const(K28_ONE));   // xi t + 1
+    z0 = f_vred(z0);
+    if (live) {
+        rec_store(rec(base + c), z0);
+        rec_store(rec(base + 8 + c), z1);
+    }
+}
+
+// batched field operation on wire operands through the 28-bit core (zkp_fp_op_batch with ZKP_FP_CORE28): 0 mul, 1 add,
+// 2 sub, 3 neg, 4 square, 5 invert (0 gives 0).  Reference: Fp::mul / add / sub / neg / square / invert, src/fp.rs:352-455.
+__global__ void k_fp28_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fp28 x, y, r;
     fp28_from_wire(x, a + 6 * i);
-    fp28_from_wire(y, b + 6 * i);
-    fp28_mul(r, x, y);
+    if (op <= 2) fp28_from_wire(y, b + 6 * i);
+    switch (op) {
+        case 0: fp28_mul(r, x, y); break;
+        case 1: f_add(r, x, y); break;
+        case 2: f_sub(r, x, y); break;
+        case 3: r = c_neg(x); break;
+        case 4: fp28_mul(r, x, x); break;
+        default: r = f_inv(x); break;
+    }
     fp28_to_wire(out + 6 * i, r);
 }
 
@@ -1242,6 +1506,61 @@ hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, co
     });
 }
 
+// nsq compressed squarings of the Fp12 value in state elements [elem_in, elem_in + 12) of every check, snapshots of
+// (z2..z5) after the squarings whose bit is set in snap_mask into 12-element areas from elem_snap on
+static hipError_t run_ksq(hipStream_t s, int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_in, uint32_t elem_snap, uint32_t nsq,
+                          uint64_t snap_mask) {
+    if (!n_checks || !nsq) return hipSuccess;
+    hipLaunchKernelGGL(k_ksq, dim3((n_checks + KS_CHECKS - 1) / KS_CHECKS), dim3(64), 0, s, state, n_checks, nc, elem_in, elem_snap, nsq, snap_mask);
+    return hipGetLastError();
+}
+
+// batched inversion of `count` planes of n per-check values (k_batch_inv): few lanes with long batches, because the kernel
+// is bound by the latency of one lane's chain (610 + 3 B multiplications)
+static hipError_t run_inv(CoopDev* d, hipStream_t s, int4* state, uint32_t n, uint32_t nc, uint32_t elem_n, uint32_t elem_ninv, uint32_t count) {
+    const size_t total = (size_t)n * count;
+    if (!total) return hipSuccess;
+    uint32_t B = (uint32_t)(total / d->inv_lanes);
+    B = B < 1 ? 1 : (B > d->inv_batch ? d->inv_batch : B);
+    const size_t lanes = (total + B - 1) / B;
+    hipLaunchKernelGGL(k_batch_inv, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, state, n, nc, B | (d->inv_fermat ? 0x80000000u : 0u), elem_n,
+                       elem_ninv, count);
+    return hipGetLastError();
+}
+
+// phase C of the final exponentiation: the generated plan (tools/coopgen.py prog_fexp_c) alternates step programs of the
+// interpreter with the compressed squaring runs of the five x-power chains and the decompression of their snapshots.
+// Everything runs on pp->stream over the n checks whose state starts at pp->state (record stride nc).
+static hipError_t run_fexp_c(CoopDev* d, CoopPipe* pp, uint32_t n, uint32_t nc, uint64_t* wire_out, uint8_t* ok, int* all_ok) {
+    hipError_t e;
+    for (int i = 0; i < ZKP_FEXP_C_PLAN_LEN; i++) {
+        const ZkpPlanStep& ps = ZKP_FEXP_C_PLAN[i];
+        switch (ps.kind) {
+            case ZKP_PLAN_PROG:
+                e = run_prog(d, pp, (int)ps.a, n, nc, 1, nullptr, wire_out, ok, all_ok);
+                break;
+            case ZKP_PLAN_KSQ:
+                e = run_ksq(pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, ps.mask);
+                break;
+            case ZKP_PLAN_KDEC_A:
+                hipLaunchKernelGGL(k_kdec_a, dim3((unsigned)((2 * (size_t)n * ps.b + 63) / 64)), dim3(64), 0, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c);
+                e = hipGetLastError();
+                break;
+            case ZKP_PLAN_INV:
+                e = run_inv(d, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c);
+                break;
+            case ZKP_PLAN_KDEC_B:
+                hipLaunchKernelGGL(k_kdec_b, dim3((unsigned)((2 * (size_t)n * ps.b + 63) / 64)), dim3(64), 0, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c);
+                e = hipGetLastError();
+                break;
+            default:
+                e = hipErrorInvalidValue;
+        }
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // Final exponentiation in two phases over a super-chunk of checks that share ONE state buffer: phase A per chunk on
 // the pipelines (whatever produces ST_F, then fexp_a down to the single Fp inversion), ONE batched inversion over all
 // checks of the super-chunk (k_batch_inv is latency bound: per 2^16-check chunk it would leave the GPU idle for ~1.5 ms),
@@ -1259,27 +1578,19 @@ static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_line
             return phase_a(&v, sb + base, n, (uint32_t)ns);
         });
         if (e != hipSuccess) return e;
-        // checks per lane: the kernel is bound by the latency of one lane's chain (610 + 3 B multiplications), so it
-        // runs on few lanes (2^15 by default) and batches the rest
-        uint32_t B = (uint32_t)(ns / d->inv_lanes);
-        B = B < 1 ? 1 : (B > d->inv_batch ? d->inv_batch : B);
-        const size_t lanes = (ns + B - 1) / B;
-        hipLaunchKernelGGL(k_batch_inv, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, d->big_state, (uint32_t)ns, (uint32_t)ns,
-                           B | (d->inv_fermat ? 0x80000000u : 0u));
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        // phase C needs no line buffer: one launch over a large super-chunk has no per-chunk tails (-1 % at 2^20
+        if ((e = run_inv(d, s, d->big_state, (uint32_t)ns, (uint32_t)ns, ZKP_COOP_ST_N, ZKP_COOP_ST_NINV, 1)) != hipSuccess) return e;
+        // phase C needs no line buffer: one pass over a large super-chunk has no per-chunk tails (-1 % at 2^20
         // checks); small ones do better per chunk on the two pipelines (-1 % at 2^17)
         if (d->c_single && ns > d->c_single_min) {
             CoopPipe v = d->pipe[0];
             v.state = d->big_state;
             v.stream = s;
-            e = run_prog(d, &v, ZKP_PROG_FEXP_C, (uint32_t)ns, (uint32_t)ns, 1, nullptr, out ? out + 72 * sb : nullptr, ok ? ok + sb : nullptr, all_ok);
+            e = run_fexp_c(d, &v, (uint32_t)ns, (uint32_t)ns, out ? out + 72 * sb : nullptr, ok ? ok + sb : nullptr, all_ok);
         } else {
             e = for_chunks(d, ns, 1, false, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
                 CoopPipe v = *pp;
                 v.state = d->big_state + 4 * base;
-                return run_prog(d, &v, ZKP_PROG_FEXP_C, n, (uint32_t)ns, 1, nullptr, out ? out + 72 * (sb + base) : nullptr,
-                                ok ? ok + sb + base : nullptr, all_ok);
+                return run_fexp_c(d, &v, n, (uint32_t)ns, out ? out + 72 * (sb + base) : nullptr, ok ? ok + sb + base : nullptr, all_ok);
             });
         }
         if (e != hipSuccess) return e;
@@ -1314,27 +1625,61 @@ hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, c
     });
 }
 
-// timing hook: run one of the synthetic programs (tools/coopgen.py prog_timing) over n checks
-hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, float* ms) {
+// zkp_tower_op_batch on the cooperative family: `ab` holds the n a-records followed by the n b-records (wire format);
+// op as in zkp_tower_op (include/zkp_pairings.h).  The cyclotomic power g^(2^repeat) takes the route of the final
+// exponentiation's x-power chains: wire -> state, one compressed squaring run with a single snapshot, decompression, -> wire.
+hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, uint32_t repeat, uint64_t* out, hipStream_t s) {
+    CoopDev* d = (CoopDev*)st->d_prog;
+    static const int progs[11] = {ZKP_PROG_TW_FP2_MUL, ZKP_PROG_TW_FP2_SQR, ZKP_PROG_TW_FP6_MUL, ZKP_PROG_TW_FP6_SQR, ZKP_PROG_TW_FP12_FROB,
+                                  ZKP_PROG_TW_FP12_MUL, ZKP_PROG_TW_FP12_SQR, ZKP_PROG_TW_FP12_014, ZKP_PROG_TW_FP12_FROB, ZKP_PROG_TW_FP12_CONJ,
+                                  ZKP_PROG_TW_CYC_SQR};
+    if (op < 0 || op > 11 || n > 0x3fffffffu) return hipErrorInvalidValue;
+    hipError_t e;
+    for (size_t base = 0; base < n; base += d->chunk) {
+        const uint32_t m = (uint32_t)(n - base < d->chunk ? n - base : d->chunk);
+        CoopPipe v = d->pipe[0];
+        v.stream = s;
+        if (op <= 10) {
+            if ((e = run_prog(d, &v, progs[op], m, m, 1, ab + 72 * base, out + 72 * base, nullptr, nullptr, 0, (uint32_t)n)) != hipSuccess) return e;
+            continue;
+        }
+        if (repeat < 1 || repeat > 64) return hipErrorInvalidValue;
+        if ((e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, (size_t)ST_SIZE * d->chunk * 64)) != hipSuccess) return e;
+        v.state = d->pipe[0].state;
+        if ((e = run_prog(d, &v, ZKP_PROG_TW_TO_STATE, m, m, 1, ab + 72 * base, nullptr, nullptr, nullptr)) != hipSuccess) return e;
+        if ((e = run_ksq(s, v.state, m, m, 0, ZKP_COOP_ST_SNAP, repeat, 1ull << (repeat - 1))) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_kdec_a, dim3((2 * m + 63) / 64), dim3(64), 0, s, v.state, m, m, (uint32_t)ZKP_COOP_ST_SNAP, 1u, (uint32_t)ZKP_COOP_ST_KN);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = run_inv(d, s, v.state, m, m, ZKP_COOP_ST_KN, ZKP_COOP_ST_KNINV, 1)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_kdec_b, dim3((2 * m + 63) / 64), dim3(64), 0, s, v.state, m, m, (uint32_t)ZKP_COOP_ST_SNAP, 1u, (uint32_t)ZKP_COOP_ST_KNINV);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = run_prog(d, &v, ZKP_PROG_TW_FROM_SNAP, m, m, 1, nullptr, out + 72 * base, nullptr, nullptr)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// timing hook (diagnostic): one of the synthetic programs (tools/coopgen.py prog_timing; which 0..8) or 400 squarings of the
+// compressed squaring-run kernel (which 9) over n checks, on the caller's stream, timed with the events handed in
+hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, hipEvent_t e0, hipEvent_t e1, float* ms) {
     CoopDev* d = (CoopDev*)st->d_prog;
     static const int ids[9] = {ZKP_PROG_TIME_T1, ZKP_PROG_TIME_T3, ZKP_PROG_TIME_T3E, ZKP_PROG_TIME_T6, ZKP_PROG_TIME_T12, ZKP_PROG_TIME_LIN,
                                ZKP_PROG_TIME_CYC, ZKP_PROG_TIME_CYCSD, ZKP_PROG_TIME_FILL};
-    if (which < 0 || which >= 9) return hipErrorInvalidValue;
-    CoopPipe* pp = &d->pipe[0];
-    hipError_t e = ensure_buf(&pp->state, &pp->state_bytes, (size_t)ST_SIZE * n * 64);
+    if (which < 0 || which > 9 || !n || n > 0x7fffffffu) return hipErrorInvalidValue;
+    hipError_t e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, (size_t)ST_SIZE * n * 64);
     if (e != hipSuccess) return e;
-    hipEvent_t e0, e1;
-    if ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess) return e;
-    (void)s;
-    if ((e = run_prog(d, pp, ids[which], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr)) != hipSuccess) return e;
-    (void)hipEventRecord(e0, pp->stream);
-    if ((e = run_prog(d, pp, ids[which], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr)) != hipSuccess) return e;
-    (void)hipEventRecord(e1, pp->stream);
-    (void)hipEventSynchronize(e1);
-    (void)hipEventElapsedTime(ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return hipSuccess;
+    CoopPipe v = d->pipe[0];
+    v.stream = s;
+    auto once = [&]() -> hipError_t {
+        if (which == 9) return run_ksq(s, v.state, (uint32_t)n, (uint32_t)n, 0, 12, 400, 1ull << 63);
+        return run_prog(d, &v, ids[which], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
+    };
+    if ((e = hipMemsetAsync(v.state, 0, (size_t)ST_SIZE * n * 64, s)) != hipSuccess) return e;
+    if ((e = once()) != hipSuccess) return e;
+    if ((e = hipEventRecord(e0, s)) != hipSuccess) return e;
+    if ((e = once()) != hipSuccess) return e;
+    if ((e = hipEventRecord(e1, s)) != hipSuccess) return e;
+    if ((e = hipEventSynchronize(e1)) != hipSuccess) return e;
+    return hipEventElapsedTime(ms, e0, e1);
 }
 
 hipError_t coop_g1_valid(const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s) {
@@ -1359,9 +1704,10 @@ hipError_t coop_g2_mul(const uint64_t* base, size_t stride, const uint64_t* sc, 
     return hipGetLastError();
 }
 
-hipError_t coop_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, hipStream_t s) {
+hipError_t coop_fp28_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_fp28_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, n, out);
+    if (op < 0 || op > 5) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_fp28_op, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, op, a, b, n, out);
     return hipGetLastError();
 }
 

@@ -21,14 +21,16 @@ void coop_free(CoopState* st);
 bool coop_selected(const CoopState* st, int kind);
 // pairs per check the cooperative path takes (checks with more than eight pairs run in groups of eight)
 bool coop_supports_k(size_t k);
-// test hook: 28-bit-limb Montgomery multiply on wire operands
-hipError_t coop_fp28_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, hipStream_t s);
+// batched Fp operation on wire operands through the 28-bit core: op 0 mul, 1 add, 2 sub, 3 neg, 4 square, 5 invert
+hipError_t coop_fp28_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, hipStream_t s);
 // G1/G2 is_valid on the 28-bit core (status 0 / 1 / 2)
 hipError_t coop_g1_valid(const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s);
 hipError_t coop_g2_valid(const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s);
 hipError_t coop_g1_mul(const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf, hipStream_t s);
 hipError_t coop_g2_mul(const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf, hipStream_t s);
-hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, float* ms);
+// one tower operation per record (zkp_tower_op_batch); ab = n a-records followed by n b-records
+hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, uint32_t repeat, uint64_t* out, hipStream_t s);
+hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, hipEvent_t e0, hipEvent_t e1, float* ms);
 hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks,
                        size_t k, uint64_t* out, hipStream_t s);
 // out (wire Gt), ok (per element Gt == identity) and all_ok (AND-ed into *all_ok) are each optional

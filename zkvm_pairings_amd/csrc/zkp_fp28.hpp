@@ -72,6 +72,39 @@ __device__ __forceinline__ void acc_reduce(int32_t* out, Acc& acc) {
     out[NL - 1] = (int32_t)v;
 }
 
+// Montgomery product in product-scanning order: out = (a1 b1 [+ a2 b2]) 2^-392 mod p, the SAME limbs acc_mul + acc_reduce
+// give (the m_i and the surviving columns are the same integers), but with every operand in registers only ONE 64-bit
+// column is live at a time: column k collects its a_i b_(k-i) and m_i p_(k-i), yields m_k (k < 14) or a balanced output
+// limb (k >= 14), and its carry is the next column's initial value - no 27-column accumulator (54 VGPRs) and no
+// separate carry additions.  For routines whose operands are all in registers (k_ksq, the line precomputation).
+template <bool TWO>
+__device__ __forceinline__ void mont_mul_ps(int32_t* out, const int32_t* a1, const int32_t* b1, const int32_t* a2, const int32_t* b2) {
+    int32_t m[NL];
+    int64_t col = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; k++) {
+        const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
+#pragma unroll
+        for (int i = lo; i <= hi; i++) {
+            col += (int64_t)a1[i] * (int64_t)b1[k - i];
+            if (TWO) col += (int64_t)a2[i] * (int64_t)b2[k - i];
+        }
+#pragma unroll
+        for (int i = lo; i <= hi; i++)
+            if (i != k) col += (int64_t)m[i] * (int64_t)K28_P[k - i];
+        if (k < NL) {
+            m[k] = (int32_t)(((uint32_t)col * ZKP28_PINV) & (uint32_t)MASK);
+            col += (int64_t)m[k] * (int64_t)K28_P[0];
+            col >>= W;                                  // the low 28 bits are zero now
+        } else {
+            const int64_t t = col + (1ll << (W - 1));
+            out[k - NL] = (int32_t)((uint32_t)t & (uint32_t)MASK) - (1 << (W - 1));
+            col = t >> W;
+        }
+    }
+    out[NL - 1] = (int32_t)col;
+}
+
 // one-pass weak normalisation of limb-wise sums: |in| < 2^31  ->  |out| <= 2^27 + 16
 __device__ __forceinline__ void weak_norm(int32_t* x) {
     int32_t c[NL];

@@ -225,15 +225,53 @@ __global__ void __launch_bounds__(TPB) k_g2_mul(const uint64_t* base, size_t str
     if (out_inf) out_inf[i] = fin ? 0 : 1;
 }
 
-// zkVM precompile shape: op 0 = mul, 1 = add on canonical operands (src/fp.rs:376,443)
+// batched field operation on canonical operands: 0 mul, 1 add (the zkVM precompile's two ops, src/fp.rs:376,443),
+// 2 sub, 3 neg, 4 square, 5 invert (0 gives 0; the reference returns None, src/fp.rs:307-319)
 __global__ void k_fp_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fp x, y, r;
     fp_load(&x, a + 6 * i);
-    fp_load(&y, b + 6 * i);
-    if (op == 0) fp_mul(&r, &x, &y); else fp_add(&r, &x, &y);
+    if (op <= 2) fp_load(&y, b + 6 * i);
+    switch (op) {
+        case 0: fp_mul(&r, &x, &y); break;
+        case 1: fp_add(&r, &x, &y); break;
+        case 2: fp_sub(&r, &x, &y); break;
+        case 3: fp_neg(&r, &x); break;
+        case 4: fp_sqr(&r, &x); break;
+        default: if (!fp_inv(&r, &x)) fp_zero(&r); break;
+    }
     fp_store(out + 6 * i, &r);
+}
+
+// one tower operation per 72-u64 record (zkp_tower_op_batch, thread family): smaller tower elements occupy the leading
+// coefficients of a record, the rest of the result is zero
+__global__ void __launch_bounds__(TPB) k_tower_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint32_t repeat, uint64_t* out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    Fp12 x, y, r;
+    fp12_load(&x, a + 72 * i);
+    if (b) fp12_load(&y, b + 72 * i);
+    fp6_zero(&r.c0);
+    fp6_zero(&r.c1);
+    switch (op) {
+        case ZKP_TOWER_FP2_MUL: fp2_mul(&r.c0.c0, &x.c0.c0, &y.c0.c0); break;
+        case ZKP_TOWER_FP2_SQUARE: fp2_sqr(&r.c0.c0, &x.c0.c0); break;
+        case ZKP_TOWER_FP6_MUL: fp6_mul(&r.c0, &x.c0, &y.c0); break;
+        case ZKP_TOWER_FP6_SQUARE: fp6_sqr(&r.c0, &x.c0); break;
+        case ZKP_TOWER_FP6_FROBENIUS: fp6_frob(&r.c0, &x.c0); break;
+        case ZKP_TOWER_FP12_MUL: fp12_mul(&r, &x, &y); break;
+        case ZKP_TOWER_FP12_SQUARE: fp12_sqr(&r, &x); break;
+        case ZKP_TOWER_FP12_MUL_BY_014: fp12_mul_by_014(&r, &x, &y.c0.c0, &y.c0.c1, &y.c0.c2); break;
+        case ZKP_TOWER_FP12_FROBENIUS: fp12_frob(&r, &x); break;
+        case ZKP_TOWER_FP12_CONJUGATE: fp12_conj(&r, &x); break;
+        case ZKP_TOWER_FP12_CYCLOTOMIC_SQUARE: fp12_cyclotomic_square(&r, &x); break;
+        default:
+            r = x;
+            for (uint32_t k = 0; k < repeat; k++) { Fp12 t; fp12_cyclotomic_square(&t, &r); r = t; }
+            break;
+    }
+    fp12_store(out + 72 * i, &r);
 }
 
 // ---- uncompressed byte codec: nfp big-endian 48-byte field elements per point (2 for G1, 4 for G2).
@@ -302,7 +340,8 @@ struct zkp_ctx {
     // grow-only device workspace for the host-pointer API
     void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int* d_flag = nullptr;
+    int* d_flag = nullptr;      // [0] product check result, [1] AND flag of the host entry points, [2] sticky validation word of the *_dev calls
+    hipEvent_t ws_busy = nullptr;   // recorded at the end of every *_dev call: the next call (on whatever stream) waits for it
     uint64_t* prod = nullptr;   // Fp12 records of the product tree (zkp_fp12_product / zkp_miller_product)
     size_t prod_cap = 0;
     // host-pointer pairing entry points on large batches: slices of host_slice pairs, two workspace slots, copies of
@@ -341,6 +380,13 @@ int ensure(zkp_ctx* c, int slot, size_t bytes) {
 
 inline unsigned grid_for(size_t n, int tpb) { return (unsigned)((n + tpb - 1) / tpb); }
 
+// status of a call into the cooperative family: the HIP error (launch configuration, out of memory, ...) goes to zkp_last_error
+int coop_rc(zkp_ctx* c, const char* what, hipError_t e) {
+    if (e == hipSuccess) return ZKP_OK;
+    c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? ZKP_ERR_OOM : ZKP_ERR_HIP;
+}
+
 int bind(zkp_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     return ZKP_OK;
@@ -363,7 +409,7 @@ int miller_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t
         return ZKP_OK;
     }
     if (zkp::coop_selected(&c->coop, c->kernel) && zkp::coop_supports_k(k))
-        return zkp::coop_miller(&c->coop, g1, g2, i1, i2, n_checks, k, out, s) == hipSuccess ? ZKP_OK : (c->err = "coop_miller launch failed", ZKP_ERR_HIP);
+        return coop_rc(c, "coop_miller", zkp::coop_miller(&c->coop, g1, g2, i1, i2, n_checks, k, out, s));
     hipLaunchKernelGGL(k_miller, dim3(grid_for(n_checks, TPB)), dim3(TPB), 0, s, g1, g2, i1, i2, n_checks, k, out);
     HIPCHK(c, hipGetLastError());
     return ZKP_OK;
@@ -371,7 +417,7 @@ int miller_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t
 int final_exp_dev(zkp_ctx* c, const uint64_t* f, size_t n, uint64_t* out, hipStream_t s) {
     if (n == 0) return ZKP_OK;
     if (zkp::coop_selected(&c->coop, c->kernel))
-        return zkp::coop_final_exp(&c->coop, f, n, out, nullptr, nullptr, s) == hipSuccess ? ZKP_OK : (c->err = "coop_final_exp launch failed", ZKP_ERR_HIP);
+        return coop_rc(c, "coop_final_exp", zkp::coop_final_exp(&c->coop, f, n, out, nullptr, nullptr, s));
     hipLaunchKernelGGL(k_final_exp, dim3(grid_for(n, TPB)), dim3(TPB), 0, s, f, n, out);
     HIPCHK(c, hipGetLastError());
     return ZKP_OK;
@@ -384,7 +430,7 @@ int pairing_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_
     }
     if (n_checks == 0) return ZKP_OK;
     if (zkp::coop_selected(&c->coop, c->kernel) && zkp::coop_supports_k(k))
-        return zkp::coop_pairing(&c->coop, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok, s) == hipSuccess ? ZKP_OK : (c->err = "coop_pairing launch failed", ZKP_ERR_HIP);
+        return coop_rc(c, "coop_pairing", zkp::coop_pairing(&c->coop, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok, s));
     hipLaunchKernelGGL(k_pairing, dim3(grid_for(n_checks, TPB)), dim3(TPB), 0, s, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok);
     HIPCHK(c, hipGetLastError());
     return ZKP_OK;
@@ -406,7 +452,7 @@ int fp12_product_inplace(zkp_ctx* c, uint64_t* buf, size_t n, hipStream_t s) {
     while (n > 1) {
         const size_t h = (n + 1) / 2, m = n - h;
         if (coop) {
-            if (zkp::coop_fp12_mul_pairs(&c->coop, buf, m, h, s) != hipSuccess) { c->err = "coop_fp12_mul_pairs launch failed"; return ZKP_ERR_HIP; }
+            if (int rc = coop_rc(c, "coop_fp12_mul_pairs", zkp::coop_fp12_mul_pairs(&c->coop, buf, m, h, s))) return rc;
         } else {
             hipLaunchKernelGGL(k_fp12_mul_pairs, dim3(grid_for(m, TPB)), dim3(TPB), 0, s, buf, m, h);
             HIPCHK(c, hipGetLastError());
@@ -596,14 +642,21 @@ int stage_pairs(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_
 namespace {
 struct HostCall {
     zkp_ctx* c;
-    ~HostCall() { if (c && c->stream) (void)hipStreamSynchronize(c->stream); }
+    explicit HostCall(zkp_ctx* ctx) : c(ctx) {   // earlier *_dev calls may still be using the workspace on other streams
+        if (c && c->stream && c->ws_busy) (void)hipStreamWaitEvent(c->stream, c->ws_busy, 0);
+    }
+    ~HostCall() {
+        if (!c || !c->stream) return;
+        if (c->ws_busy) (void)hipEventRecord(c->ws_busy, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+    }
 };
 }  // namespace
 
 // =============================================================================== C ABI
 extern "C" {
 
-int zkp_abi_version(void) { return 1; }
+int zkp_abi_version(void) { return 2; }
 
 const char* zkp_strerror(int status) {
     switch (status) {
@@ -629,7 +682,8 @@ int zkp_init(int device, zkp_ctx** out_ctx) {
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-        hipEventCreate(&c->ev1) != hipSuccess || hipMalloc((void**)&c->d_flag, 2 * sizeof(int)) != hipSuccess) {
+        hipEventCreate(&c->ev1) != hipSuccess || hipEventCreateWithFlags(&c->ws_busy, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void**)&c->d_flag, 3 * sizeof(int)) != hipSuccess || hipMemset(c->d_flag, 0, 3 * sizeof(int)) != hipSuccess) {
         zkp_free(c);
         return ZKP_ERR_NO_DEVICE;
     }
@@ -669,6 +723,7 @@ void zkp_free(zkp_ctx* c) {
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ws_busy) (void)hipEventDestroy(c->ws_busy);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -691,66 +746,102 @@ int zkp_device_info(const zkp_ctx* c, int* cus, int* clock_khz, char* name, size
 
 // ---------------------------------------------------------------- device-pointer API
 #define S(stream) ((hipStream_t)(stream))
+namespace {
+// The workspace inside a ctx (line buffers, per-check state, product tree, flags) is shared by every call: a *_dev call
+// first makes its stream wait for the previous call's last use of the workspace - which may have been queued on ANOTHER
+// stream - and leaves an event behind for the next one.  Calls on one stream order themselves anyway.
+struct DevCall {
+    zkp_ctx* c;
+    hipStream_t s;
+    int rc;
+    DevCall(zkp_ctx* ctx, void* stream) : c(ctx), s((hipStream_t)stream), rc(ZKP_OK) {
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, c->ws_busy, 0);
+        if (e != hipSuccess) { c->err = std::string("DevCall: ") + hipGetErrorString(e); rc = ZKP_ERR_HIP; }
+    }
+    ~DevCall() { if (rc == ZKP_OK) (void)hipEventRecord(c->ws_busy, s); }
+};
+// validation mode on the device-pointer entry points: a range check of the inputs on the caller's stream that ORs into a
+// sticky word (no host synchronisation); zkp_take_validation_status_dev reads and clears it
+int validate_on_stream(zkp_ctx* c, const void* d, size_t n_fp, hipStream_t s) {
+    if (!c->validate || !n_fp || !d) return ZKP_OK;
+    hipLaunchKernelGGL(k_check_canonical, dim3(grid_for(n_fp, 256)), dim3(256), 0, s, (const uint64_t*)d, n_fp, c->d_flag + 2);
+    HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
+}
+}  // namespace
+#define DEV_ENTER(ctx, stream)      \
+    DevCall dc__((ctx), (stream)); \
+    if (dc__.rc) return dc__.rc
+// range limits shared by the entry points: every per-launch count stays in 32 bits
+static inline bool too_many(size_t n, size_t k = 1) { return n > 0x7fffffffu || k > 0xffffu || (k && n > 0x7fffffffu / k); }
+
 int zkp_pairing_batch_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n, void* out, void* stream) {
-    if (!c || (n && (!g1 || !g2 || !out))) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || too_many(n) || (n && (!g1 || !g2 || !out))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    int rc;
+    if ((rc = validate_on_stream(c, g1, n * 2, S(stream))) || (rc = validate_on_stream(c, g2, n * 4, S(stream)))) return rc;
     return pairing_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n, 1, (uint64_t*)out, nullptr, nullptr, S(stream));
 }
 int zkp_multi_miller_loop_batch_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n_checks, size_t k,
                                     void* out, void* stream) {
-    if (!c || (n_checks && (!out || (k && (!g1 || !g2))))) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || too_many(n_checks, k) || (n_checks && (!out || (k && (!g1 || !g2))))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    int rc;
+    if ((rc = validate_on_stream(c, g1, n_checks * k * 2, S(stream))) || (rc = validate_on_stream(c, g2, n_checks * k * 4, S(stream)))) return rc;
     return miller_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n_checks, k, (uint64_t*)out, S(stream));
 }
 int zkp_final_exponentiation_batch_dev(zkp_ctx* c, const void* f, size_t n, void* out, void* stream) {
-    if (!c || (n && (!f || !out))) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || too_many(n) || (n && (!f || !out))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    if (int rc = validate_on_stream(c, f, n * 12, S(stream))) return rc;
     return final_exp_dev(c, (const uint64_t*)f, n, (uint64_t*)out, S(stream));
 }
 int zkp_fp12_product_dev(zkp_ctx* c, const void* f, size_t n, void* out, void* stream) {
-    if (!c || !out || (n && !f) || n > 0x7fffffffu) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || !out || (n && !f) || too_many(n)) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    if (int rc = validate_on_stream(c, f, n * 12, S(stream))) return rc;
     return fp12_product_dev(c, (const uint64_t*)f, n, (uint64_t*)out, S(stream));
 }
 int zkp_miller_product_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n, void* out_ml, void* stream) {
-    if (!c || !out_ml || (n && (!g1 || !g2)) || n > 0x7fffffffu) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || !out_ml || (n && (!g1 || !g2)) || too_many(n)) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    int rc;
+    if ((rc = validate_on_stream(c, g1, n * 2, S(stream))) || (rc = validate_on_stream(c, g2, n * 4, S(stream)))) return rc;
     return miller_product_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n, (uint64_t*)out_ml, S(stream));
 }
 int zkp_pairing_product_check_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n, void* out_gt,
                                   void* is_one, void* stream) {
-    if (!c || (n && (!g1 || !g2)) || n > 0x7fffffffu) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || (n && (!g1 || !g2)) || too_many(n)) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    int rc;
+    if ((rc = validate_on_stream(c, g1, n * 2, S(stream))) || (rc = validate_on_stream(c, g2, n * 4, S(stream)))) return rc;
     return product_check_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n, (uint64_t*)out_gt, (int*)is_one,
                              S(stream));
 }
 int zkp_pairing_check_batch_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n_checks, size_t k,
                                 void* ok, void* all_ok, void* stream) {
-    if (!c || (n_checks && k && (!g1 || !g2))) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || too_many(n_checks, k) || (n_checks && k && (!g1 || !g2))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    int rc;
+    if ((rc = validate_on_stream(c, g1, n_checks * k * 2, S(stream))) || (rc = validate_on_stream(c, g2, n_checks * k * 4, S(stream)))) return rc;
     return pairing_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n_checks, k, nullptr, (uint8_t*)ok,
                        (int*)all_ok, S(stream));
 }
 int zkp_pairing_gt_check_batch_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n_checks, size_t k,
                                    void* out_gt, void* ok, void* all_ok, void* stream) {
-    if (!c || (n_checks && k && (!g1 || !g2))) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || too_many(n_checks, k) || (n_checks && k && (!g1 || !g2))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    int rc;
+    if ((rc = validate_on_stream(c, g1, n_checks * k * 2, S(stream))) || (rc = validate_on_stream(c, g2, n_checks * k * 4, S(stream)))) return rc;
     return pairing_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n_checks, k, (uint64_t*)out_gt,
                        (uint8_t*)ok, (int*)all_ok, S(stream));
 }
 int zkp_g1_is_valid_batch_dev(zkp_ctx* c, const void* g1, const void* inf, size_t n, void* status, void* stream) {
-    if (!c || (n && (!g1 || !status))) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || too_many(n) || (n && (!g1 || !status))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
     if (!n) return ZKP_OK;
+    if (int rc = validate_on_stream(c, g1, n * 2, S(stream))) return rc;
     if (zkp::coop_selected(&c->coop, c->kernel)) {
         HIPCHK(c, zkp::coop_g1_valid((const uint64_t*)g1, (const uint8_t*)inf, n, (uint8_t*)status, S(stream)));
         return ZKP_OK;
@@ -760,10 +851,10 @@ int zkp_g1_is_valid_batch_dev(zkp_ctx* c, const void* g1, const void* inf, size_
     return ZKP_OK;
 }
 int zkp_g2_is_valid_batch_dev(zkp_ctx* c, const void* g2, const void* inf, size_t n, void* status, void* stream) {
-    if (!c || (n && (!g2 || !status))) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || too_many(n) || (n && (!g2 || !status))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
     if (!n) return ZKP_OK;
+    if (int rc = validate_on_stream(c, g2, n * 4, S(stream))) return rc;
     if (zkp::coop_selected(&c->coop, c->kernel)) {
         HIPCHK(c, zkp::coop_g2_valid((const uint64_t*)g2, (const uint8_t*)inf, n, (uint8_t*)status, S(stream)));
         return ZKP_OK;
@@ -773,10 +864,10 @@ int zkp_g2_is_valid_batch_dev(zkp_ctx* c, const void* g2, const void* inf, size_
     return ZKP_OK;
 }
 int zkp_g1_mul_batch_dev(zkp_ctx* c, const void* base, size_t stride, const void* sc, size_t n, void* out, void* out_inf, void* stream) {
-    if (!c || (n && (!base || !sc || !out)) || (stride != 0 && stride != 12)) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || too_many(n) || (n && (!base || !sc || !out)) || (stride != 0 && stride != 12)) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
     if (!n) return ZKP_OK;
+    if (int rc = validate_on_stream(c, base, (stride ? n : 1) * 2, S(stream))) return rc;
     if (zkp::coop_selected(&c->coop, c->kernel)) {
         HIPCHK(c, zkp::coop_g1_mul((const uint64_t*)base, stride, (const uint64_t*)sc, n, (uint64_t*)out, (uint8_t*)out_inf, S(stream)));
         return ZKP_OK;
@@ -786,16 +877,28 @@ int zkp_g1_mul_batch_dev(zkp_ctx* c, const void* base, size_t stride, const void
     return ZKP_OK;
 }
 int zkp_g2_mul_batch_dev(zkp_ctx* c, const void* base, size_t stride, const void* sc, size_t n, void* out, void* out_inf, void* stream) {
-    if (!c || (n && (!base || !sc || !out)) || (stride != 0 && stride != 24)) return ZKP_ERR_ARG;
-    int rc = bind(c);
-    if (rc) return rc;
+    if (!c || too_many(n) || (n && (!base || !sc || !out)) || (stride != 0 && stride != 24)) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
     if (!n) return ZKP_OK;
+    if (int rc = validate_on_stream(c, base, (stride ? n : 1) * 4, S(stream))) return rc;
     if (zkp::coop_selected(&c->coop, c->kernel)) {
         HIPCHK(c, zkp::coop_g2_mul((const uint64_t*)base, stride, (const uint64_t*)sc, n, (uint64_t*)out, (uint8_t*)out_inf, S(stream)));
         return ZKP_OK;
     }
     hipLaunchKernelGGL(k_g2_mul, dim3(grid_for(n, TPB)), dim3(TPB), 0, S(stream), (const uint64_t*)base, stride, (const uint64_t*)sc, n, (uint64_t*)out, (uint8_t*)out_inf);
     HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
+}
+// validation mode of the device-pointer entry points: *bad = 1 if any *_dev call since the last query saw a field
+// element >= p in its inputs (the results of such a call are unspecified).  Waits for `stream`, then clears the word.
+int zkp_take_validation_status_dev(zkp_ctx* c, void* stream, int* bad) {
+    if (!c || !bad) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    int v = 0;
+    HIPCHK(c, hipMemcpyAsync(&v, c->d_flag + 2, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
+    HIPCHK(c, hipMemsetAsync(c->d_flag + 2, 0, sizeof(int), S(stream)));
+    HIPCHK(c, hipStreamSynchronize(S(stream)));
+    *bad = v ? 1 : 0;
     return ZKP_OK;
 }
 
@@ -805,7 +908,7 @@ int zkp_pairing_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const 
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
-    HostCall drain{c};
+    HostCall drain(c);
     if (n > c->host_slice && !c->validate) return host_sliced(c, g1, g2, inf1, inf2, n, 1, out_gt, nullptr, nullptr);
     Staged st;
     if ((rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st)) || (rc = ensure(c, 4, n * 576))) return rc;
@@ -820,7 +923,7 @@ int zkp_multi_miller_loop_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* 
     if (!n_checks) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
-    HostCall drain{c};
+    HostCall drain(c);
     Staged st = {nullptr, nullptr, nullptr, nullptr};
     if (k && (rc = stage_pairs(c, g1, g2, inf1, inf2, n_checks * k, &st))) return rc;
     if ((rc = ensure(c, 4, n_checks * 576))) return rc;
@@ -834,7 +937,7 @@ int zkp_final_exponentiation_batch(zkp_ctx* c, const uint64_t* f, size_t n, uint
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
-    HostCall drain{c};
+    HostCall drain(c);
     if ((rc = ensure(c, 5, n * 576)) || (rc = ensure(c, 4, n * 576))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->buf[5], f, n * 576, hipMemcpyHostToDevice, c->stream));
     if ((rc = validate_dev(c, (const uint64_t*)c->buf[5], n * 12))) return rc;
@@ -848,7 +951,7 @@ int zkp_fp12_product(zkp_ctx* c, const uint64_t* f, size_t n, uint64_t* out) {
     if (!n) { memcpy(out, GT_IDENTITY, 576); return ZKP_OK; }
     int rc = bind(c);
     if (rc) return rc;
-    HostCall drain{c};
+    HostCall drain(c);
     if ((rc = ensure_prod(c, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->prod, f, n * 576, hipMemcpyHostToDevice, c->stream));
     if ((rc = validate_dev(c, c->prod, n * 12))) return rc;
@@ -862,7 +965,7 @@ int zkp_miller_product(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const
     if (!n) { memcpy(out_ml, GT_IDENTITY, 576); return ZKP_OK; }
     int rc = bind(c);
     if (rc) return rc;
-    HostCall drain{c};
+    HostCall drain(c);
     Staged st = {nullptr, nullptr, nullptr, nullptr};
     if ((rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st))) return rc;
     if ((rc = miller_product_dev(c, st.g1, st.g2, st.i1, st.i2, n, nullptr, c->stream))) return rc;
@@ -880,7 +983,7 @@ int zkp_pairing_product_check(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2
     }
     int rc = bind(c);
     if (rc) return rc;
-    HostCall drain{c};
+    HostCall drain(c);
     Staged st = {nullptr, nullptr, nullptr, nullptr};
     if ((rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st))) return rc;
     if ((rc = ensure(c, 4, 576))) return rc;
@@ -899,7 +1002,7 @@ int zkp_pairing_check_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, 
     if (!n_checks) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
-    HostCall drain{c};
+    HostCall drain(c);
     // flags-only results need no large download: one shot is faster (measured) until the upload workspace gets large
     if (k && n_checks * k > 8 * c->host_slice && !c->validate) return host_sliced(c, g1, g2, inf1, inf2, n_checks, k, nullptr, ok, all_ok);
     Staged st = {nullptr, nullptr, nullptr, nullptr};
@@ -918,7 +1021,7 @@ static int valid_host(zkp_ctx* c, int which, const uint64_t* pts, const uint8_t*
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
-    HostCall drain{c};
+    HostCall drain(c);
     size_t sz = which == 1 ? 96 : 192;
     if ((rc = ensure(c, 0, n * sz)) || (rc = ensure(c, 6, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->buf[0], pts, n * sz, hipMemcpyHostToDevice, c->stream));
@@ -945,7 +1048,7 @@ static int mul_host(zkp_ctx* c, int which, const uint64_t* base, size_t stride, 
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
-    HostCall drain{c};
+    HostCall drain(c);
     size_t nb = stride ? n : 1;
     if ((rc = ensure(c, 0, nb * w * 8)) || (rc = ensure(c, 1, n * 32)) || (rc = ensure(c, 4, n * w * 8)) || (rc = ensure(c, 6, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->buf[0], base, nb * w * 8, hipMemcpyHostToDevice, c->stream));
@@ -970,7 +1073,7 @@ static int codec_host(zkp_ctx* c, bool decode, int nfp, const void* in, const ui
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
-    HostCall drain{c};
+    HostCall drain(c);
     const size_t nb = n * 48 * nfp;
     if ((rc = ensure(c, 0, nb)) || (rc = ensure(c, 4, nb)) || (rc = ensure(c, 2, n)) || (rc = ensure(c, 6, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->buf[0], in, nb, hipMemcpyHostToDevice, c->stream));
@@ -1008,19 +1111,24 @@ int zkp_g2_encode_batch(zkp_ctx* c, const uint64_t* g2, const uint8_t* inf, size
 }
 
 int zkp_fp_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
-    if (!c || (op != 0 && op != 1 && op != 2) || (n && (!a || !b || !out))) return ZKP_ERR_ARG;
+    const int base = op & ~ZKP_FP_CORE28;
+    const bool unary = base == ZKP_FP_NEG || base == ZKP_FP_SQUARE || base == ZKP_FP_INVERT;
+    if (!c || op < 0 || base > ZKP_FP_INVERT || n > 0x7fffffffu || (n && (!a || !out || (!unary && !b)))) return ZKP_ERR_ARG;
     if (!n) return ZKP_OK;
     int rc = bind(c);
     if (rc) return rc;
-    HostCall drain{c};
+    HostCall drain(c);
     if ((rc = ensure(c, 0, n * 48)) || (rc = ensure(c, 1, n * 48)) || (rc = ensure(c, 4, n * 48))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->buf[0], a, n * 48, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->buf[1], b, n * 48, hipMemcpyHostToDevice, c->stream));
-    if ((rc = validate_dev(c, (const uint64_t*)c->buf[0], n)) || (rc = validate_dev(c, (const uint64_t*)c->buf[1], n))) return rc;
-    if (op == 2) {  // same product through the 28-bit carry-free core of the cooperative family
-        HIPCHK(c, zkp::coop_fp28_mul((const uint64_t*)c->buf[0], (const uint64_t*)c->buf[1], n, (uint64_t*)c->buf[4], c->stream));
+    if ((rc = validate_dev(c, (const uint64_t*)c->buf[0], n))) return rc;
+    if (!unary) {
+        HIPCHK(c, hipMemcpyAsync(c->buf[1], b, n * 48, hipMemcpyHostToDevice, c->stream));
+        if ((rc = validate_dev(c, (const uint64_t*)c->buf[1], n))) return rc;
+    }
+    if (op & ZKP_FP_CORE28) {   // the 14 x 28-bit carry-free core of the cooperative family
+        HIPCHK(c, zkp::coop_fp28_op(base, (const uint64_t*)c->buf[0], (const uint64_t*)c->buf[1], n, (uint64_t*)c->buf[4], c->stream));
     } else {
-        hipLaunchKernelGGL(k_fp_op, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, op, (const uint64_t*)c->buf[0], (const uint64_t*)c->buf[1], n, (uint64_t*)c->buf[4]);
+        hipLaunchKernelGGL(k_fp_op, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, base, (const uint64_t*)c->buf[0], (const uint64_t*)c->buf[1], n, (uint64_t*)c->buf[4]);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipMemcpyAsync(out, c->buf[4], n * 48, hipMemcpyDeviceToHost, c->stream));
@@ -1028,11 +1136,101 @@ int zkp_fp_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, si
     return ZKP_OK;
 }
 
+int zkp_tower_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint32_t repeat, uint64_t* out) {
+    const bool binary = op == ZKP_TOWER_FP2_MUL || op == ZKP_TOWER_FP6_MUL || op == ZKP_TOWER_FP12_MUL || op == ZKP_TOWER_FP12_MUL_BY_014;
+    if (!c || op < 0 || op > ZKP_TOWER_FP12_CYCLOTOMIC_POW2K || n > 0x3fffffffu || (n && (!a || !out || (binary && !b)))) return ZKP_ERR_ARG;
+    if (op == ZKP_TOWER_FP12_CYCLOTOMIC_POW2K && (repeat < 1 || repeat > 64)) return ZKP_ERR_ARG;
+    if (!n) return ZKP_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    HostCall drain(c);
+    // one buffer: the a records, then the b records (the step programs read record check + n as their second operand)
+    if ((rc = ensure(c, 5, 2 * n * 576)) || (rc = ensure(c, 4, n * 576))) return rc;
+    uint64_t* d_a = (uint64_t*)c->buf[5];
+    uint64_t* d_b = d_a + 72 * n;
+    HIPCHK(c, hipMemcpyAsync(d_a, a, n * 576, hipMemcpyHostToDevice, c->stream));
+    if (binary) HIPCHK(c, hipMemcpyAsync(d_b, b, n * 576, hipMemcpyHostToDevice, c->stream));
+    if ((rc = validate_dev(c, d_a, (binary ? 2 : 1) * n * 12))) return rc;
+    if (zkp::coop_selected(&c->coop, c->kernel)) {
+        const hipError_t e = zkp::coop_tower_op(&c->coop, op, d_a, n, repeat, (uint64_t*)c->buf[4], c->stream);
+        if (e != hipSuccess) { c->err = std::string("coop_tower_op: ") + hipGetErrorString(e); return ZKP_ERR_HIP; }
+    } else {
+        hipLaunchKernelGGL(k_tower_op, dim3(grid_for(n, TPB)), dim3(TPB), 0, c->stream, op, d_a, binary ? d_b : nullptr, n, repeat, (uint64_t*)c->buf[4]);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipMemcpyAsync(out, c->buf[4], n * 576, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZKP_OK;
+}
+
+// ---------------------------------------------------------------- several GPUs behind one call
+// one host thread drives n_ctx contexts (normally one per GPU of the node; several on one GPU work
+// too), every context takes a contiguous block of the checks - a check's k pairs and its shared final exponentiation
+// stay on one GPU - uploads it on its own stream, runs the same pipeline as zkp_pairing_check_batch / zkp_pairing_batch,
+// and downloads its results; the per-context AND flags are combined on the host.  Nothing crosses xGMI: the data path
+// has no collective.  (The one-process-per-GPU form of the same call is zkp_pairing_check_batch per rank plus ONE
+// ncclAllReduce(count = 1, ncclInt32, ncclMin) of the flag - RCCL has no bitwise AND; INTEGRATION.md.)
+static int multi_impl(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
+                      size_t n_checks, size_t k, uint64_t* out_gt, uint8_t* ok, int* all_ok) {
+    if (!ctxs || n_ctx <= 0 || n_ctx > 64 || too_many(n_checks, k) || (n_checks && k && (!g1 || !g2))) return ZKP_ERR_ARG;
+    for (int j = 0; j < n_ctx; j++) {
+        if (!ctxs[j]) return ZKP_ERR_ARG;
+        for (int i = 0; i < j; i++)
+            if (ctxs[i] == ctxs[j]) return ZKP_ERR_ARG;
+    }
+    if (all_ok) *all_ok = 1;
+    if (!n_checks) return ZKP_OK;
+    int flags[64];
+    int rc = ZKP_OK, used = 0;
+    const size_t base = n_checks / n_ctx, rem = n_checks % n_ctx;
+    for (int j = 0; j < n_ctx && rc == ZKP_OK; j++) {
+        zkp_ctx* c = ctxs[j];
+        const size_t lo = j * base + ((size_t)j < rem ? j : rem), m = base + ((size_t)j < rem ? 1 : 0), p0 = lo * k;
+        flags[j] = 1;
+        used = j + 1;
+        if (!m) continue;
+        if ((rc = bind(c))) break;
+        if (c->ws_busy) (void)hipStreamWaitEvent(c->stream, c->ws_busy, 0);
+        Staged st = {nullptr, nullptr, nullptr, nullptr};
+        if (k && (rc = stage_pairs(c, g1 + 12 * p0, g2 + 24 * p0, inf1 ? inf1 + p0 : nullptr, inf2 ? inf2 + p0 : nullptr, m * k, &st))) break;
+        if ((out_gt && (rc = ensure(c, 4, m * 576))) || (rc = ensure(c, 6, m))) break;
+        if ((rc = pairing_dev(c, st.g1, st.g2, st.i1, st.i2, m, k, out_gt ? (uint64_t*)c->buf[4] : nullptr, (uint8_t*)c->buf[6], c->d_flag + 1, c->stream)))
+            break;
+        hipError_t e = hipSuccess;
+        if (out_gt) e = hipMemcpyAsync(out_gt + 72 * lo, c->buf[4], m * 576, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && ok) e = hipMemcpyAsync(ok + lo, c->buf[6], m, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&flags[j], c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->ws_busy, c->stream);
+        if (e != hipSuccess) { c->err = std::string("zkp_pairing_*_multi: ") + hipGetErrorString(e); rc = ZKP_ERR_HIP; }
+    }
+    // whatever happened, nothing may still be copying from or into the caller's arrays when the call returns
+    for (int j = 0; j < used; j++) {
+        zkp_ctx* c = ctxs[j];
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            if (rc == ZKP_OK) { c->err = "zkp_pairing_*_multi: stream synchronisation failed"; rc = ZKP_ERR_HIP; }
+        }
+    }
+    if (rc != ZKP_OK) return rc;
+    int all = 1;
+    for (int j = 0; j < used; j++) all &= flags[j] ? 1 : 0;
+    if (all_ok) *all_ok = all;
+    return ZKP_OK;
+}
+int zkp_pairing_check_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
+                                  size_t n_checks, size_t k, uint8_t* ok, int* all_ok) {
+    return multi_impl(ctxs, n_ctx, g1, g2, inf1, inf2, n_checks, k, nullptr, ok, all_ok);
+}
+int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n,
+                            uint64_t* out_gt, uint8_t* ok, int* all_ok) {
+    if (n && !out_gt) return ZKP_ERR_ARG;
+    return multi_impl(ctxs, n_ctx, g1, g2, inf1, inf2, n, 1, out_gt, ok, all_ok);
+}
+
 int zkp_time_coop_step(zkp_ctx* c, int which, size_t n, float* ms) {
     if (!c || !ms) return ZKP_ERR_ARG;
     int rc = bind(c);
     if (rc) return rc;
-    HIPCHK(c, zkp::coop_time_prog(&c->coop, which, n, c->stream, ms));
+    HIPCHK(c, zkp::coop_time_prog(&c->coop, which, n, c->stream, c->ev0, c->ev1, ms));
     return ZKP_OK;
 }
 

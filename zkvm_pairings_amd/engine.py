@@ -243,11 +243,31 @@ class PairingEngine:
         self._chk(fn(self._h, _ptr(pts), _ptr(i), n, _ptr(out)))
         return out.tobytes()
 
-    def fp_op(self, op, a, b):
-        """zkVM-precompile-shaped batched field op: op 0 = mul, 1 = add (reference src/fp.rs:376,443)."""
-        a, b = _np(a, 6), _np(b, 6)
+    FP_OPS = {"mul": 0, "add": 1, "sub": 2, "neg": 3, "square": 4, "invert": 5}
+    TOWER_OPS = {"fp2_mul": 0, "fp2_square": 1, "fp6_mul": 2, "fp6_square": 3, "fp6_frobenius": 4, "fp12_mul": 5, "fp12_square": 6,
+                 "fp12_mul_by_014": 7, "fp12_frobenius": 8, "fp12_conjugate": 9, "fp12_cyclotomic_square": 10, "fp12_cyclotomic_pow2k": 11}
+
+    def fp_op(self, op, a, b=None, core28=False):
+        """zkVM-precompile-shaped batched field op: op 0 = mul, 1 = add (reference src/fp.rs:376,443), 2 sub, 3 neg,
+        4 square, 5 invert (or the names in FP_OPS); core28 runs it on the 28-bit core of the cooperative family."""
+        op = self.FP_OPS.get(op, op)
+        a = _np(a, 6)
+        b = None if b is None else _np(b, 6)
+        if b is not None and b.shape != a.shape:
+            raise ValueError("fp_op: operand shapes differ")
         out = np.empty_like(a)
-        self._chk(self._lib.zkp_fp_op_batch(self._h, int(op), _ptr(a), _ptr(b), a.shape[0], _ptr(out)))
+        self._chk(self._lib.zkp_fp_op_batch(self._h, int(op) | (16 if core28 else 0), _ptr(a), _ptr(b), a.shape[0], _ptr(out)))
+        return out
+
+    def tower_op(self, op, a, b=None, repeat=1):
+        """one tower operation per (n,72) record on the engine's kernel family (zkp_tower_op_batch); op: name in TOWER_OPS"""
+        op = self.TOWER_OPS.get(op, op)
+        a = _np(a, 72)
+        b = None if b is None else _np(b, 72)
+        if b is not None and b.shape != a.shape:
+            raise ValueError("tower_op: operand shapes differ")
+        out = np.empty_like(a)
+        self._chk(self._lib.zkp_tower_op_batch(self._h, int(op), _ptr(a), _ptr(b), a.shape[0], int(repeat), _ptr(out)))
         return out
 
     # ------------------------------------------------------------------ torch (device-resident) API
