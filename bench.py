@@ -4,9 +4,9 @@
 One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).  The workload is BASELINE.json's: ONE batch of
 2^20 random (G1,G2) pairs, sharded in contiguous blocks over the ranks (strong scaling: 2^20 pairs on 1 GPU,
 2^17 per GPU on 8).  A step = one pass of the hot path over this rank's resident shard: fused Miller loop + final
-exponentiation -> Gt (bit-exact vs the CPU oracle on a sample) + the Gt==identity flags, then ONE
-all-reduce(MIN) of the per-rank AND flag over RCCL (the only collective the path has).  Inputs are generated on
-the GPU before the timed region and stay resident in HBM."""
+exponentiation -> Gt (bit-exact vs the CPU oracle on a sample) + the Gt==identity flags, then - when there is more
+than one rank - ONE all-reduce(MIN) of the per-rank AND flag over RCCL (the only collective the path has).  Inputs
+are generated on the GPU before the timed region and stay resident in HBM."""
 import argparse
 import json
 import os
@@ -17,12 +17,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GLOBAL_PAIRS = 1 << 20
-# algorithmic work per pairing with the reference-shaped tower =
-# 21,869 Fp-mul-equivalents x 300 32x32->64 multiply-adds (CIOS, 12 limbs)
-MACS_PER_PAIRING = 21869 * 300
-# measured on MI355X (tools/ubench_valu.hip): v_mad_u64_u32 issues one wave-instruction per ~4
-# cycles per SIMD = 16 lanes/clk/SIMD;  256 CU x 4 SIMD x 16 x 2.4 GHz
-PEAK_MACS = 256 * 4 * 16 * 2.4e9
+# algorithmic work per pairing with the reference-shaped tower = 21,869 Fp-mul-equivalents (10,140 in
+# the Miller loop, 11,116 + 613 for the one inversion in the final exponentiation) x 300 32x32->64 multiply-adds of a
+# 12-limb CIOS multiply
+FPMUL_MILLER, FPMUL_FEXP = 10140, 11116 + 613
+MACS_PER_FPMUL = 300
+MACS_PER_PAIRING = (FPMUL_MILLER + FPMUL_FEXP) * MACS_PER_FPMUL
+# measured on MI355X (tools/ubench_valu.hip): v_mad_u64_u32 issues one wave-instruction per ~4 cycles per SIMD
+# = 16 lanes/clk/SIMD;  256 CU x 4 SIMD x 16 x clock.  The datasheet clock is 2.4 GHz; under this load the chip
+# sustains less (measured live by the clock probe), so both fractions are printed.
+LANES_PER_CLK = 256 * 4 * 16
+NOMINAL_GHZ = 2.4
+PEAK_MACS = LANES_PER_CLK * NOMINAL_GHZ * 1e9
 
 
 def main():
@@ -33,9 +39,17 @@ def main():
     ap.add_argument("--pairs", type=int, default=GLOBAL_PAIRS, help="global batch, sharded over the ranks")
     ap.add_argument("--pairs-per-gpu", type=int, default=0, help="override: fixed shard per rank (weak scaling)")
     ap.add_argument("--kernel", default=os.environ.get("ZKP_KERNEL", "auto"))
-    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="pairs of the oracle leg (parity sample + all-cores baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d - launch one rank per GPU with `python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node %d ... bench.py --gpus %d`\n" % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit(2)
 
     import numpy as np
     import torch
@@ -44,11 +58,9 @@ def main():
     from zkvm_pairings_amd import dist as zdist
     from zkvm_pairings_amd import synthetic
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     # test-only knobs to rehearse N > 1 on a one-GPU box: every rank on cuda:0, gloo instead of RCCL
-    if os.environ.get("ZKP_BENCH_SHARE_GPU") == "1":
+    shared_gpu = os.environ.get("ZKP_BENCH_SHARE_GPU") == "1"
+    if shared_gpu:
         local_rank = 0
     backend = os.environ.get("ZKP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
@@ -79,13 +91,15 @@ def main():
 
     def step():
         eng.pairing_gt_check(g1, g2, 1, out_gt, ok, flag)
-        zdist.and_reduce(flag)  # AND of {0,1} flags == MIN; the only collective on the path
+        zdist.and_reduce(flag)  # AND of {0,1} flags == MIN; the only collective on the path (nothing to do on one rank)
 
+    ranks = 1
     if world > 1:
-        # establish the RCCL communicator outside the timed region even when --warmup 0 is requested
+        # establish the communicator outside the timed region even when --warmup 0 is requested
         probe = torch.ones(1, dtype=torch.int32, device=dev)
         zdist.and_reduce(probe)
         torch.cuda.synchronize()
+        ranks = dist.get_world_size()
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -101,50 +115,108 @@ def main():
     dt = zdist.max_over_ranks(dt, dev)
     all_ok = int(flag.item())
 
-    # dominant-kernel duration: HIP events recorded on the stream the kernel is launched on
-    kern_ms = eng.time_pairing(g1, g2, out_gt, 2)
-
     line = None
     if rank == 0:
+        # ---- everything below is measurement bookkeeping outside the timed region
+        # dominant-kernel duration: HIP events recorded on the stream the kernels are launched on
+        kern_ms = eng.time_pairing(g1, g2, out_gt, 2)
+
+        def timed_ms(fn, reps=2):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                r = fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps, r
+
+        # the two phases on their own (the *_dev calls fork and join on torch's current stream, so its events see them)
+        ml_ms, ml = timed_ms(lambda: eng.multi_miller_loop(g1, g2, 1))
+        fe_ms, _ = timed_ms(lambda: eng.final_exponentiation(ml))
+        del ml
+        # clock the chip sustains under this load: a one-wavefront probe on a second stream beside a pass
+        side = torch.cuda.Stream(device=dev)
+        eng.pairing_gt_check(g1, g2, 1, out_gt, ok, flag)
+        ticks, wall_khz = eng.clock_probe(side, spin_us=max(20000, int(kern_ms * 500)))
+        torch.cuda.synchronize()
+        tk = ticks.cpu().numpy()
+        sustained_ghz = float(tk[0]) / float(tk[1]) * wall_khz * 1e3 / 1e9 if tk[1] else None
+
         value = global_pairs * args.steps / dt
         achieved = (n * MACS_PER_PAIRING) / (kern_ms * 1e-3)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01", "pmc", "traffic.json")
-        if os.path.exists(tpath) and args.kernel in ("auto", "coop"):
-            with open(tpath) as tf:   # rocprofv3 PMC passes over one 2^20-pair pass, gfx950-corrected (tools/pmc_traffic.py); linear in n
-                tj = json.load(tf)
-                traffic = tj["hbm_bytes_per_step"] * n / tj["pairs_per_step"]
+        phase = lambda fpm, ms: (n * fpm * MACS_PER_FPMUL) / (ms * 1e-3) / PEAK_MACS
+        traffic = traffic_src = None
+        for rnd in ("r02", "r01"):
+            tpath = os.path.join(ROOT, "profiles", rnd, "pmc", "traffic.json")
+            if os.path.exists(tpath) and args.kernel in ("auto", "coop"):
+                with open(tpath) as tf:   # rocprofv3 PMC passes over one 2^20-pair pass, gfx950-corrected (tools/pmc_traffic.py); linear in n
+                    tj = json.load(tf)
+                    traffic = tj["hbm_bytes_per_step"] * n / tj["pairs_per_step"]
+                    traffic_src = "profiles/%s/pmc/traffic.json" % rnd
+                break
         # bit-exact parity of a seeded sample vs the CPU oracle + timing of the oracle on the host cores
         cpu = None
         parity = None
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as o  # cpu_baseline leg / checker only
-            cores = max(1, min(os.cpu_count() or 1, 16))
+            host_cores = os.cpu_count() or 1
             ns = min(args.cpu_sample, n)
             idx = torch.arange(0, n, n // ns, device=dev)[:ns]
             h1 = g1[idx].cpu().numpy().view(np.uint64)
             h2 = g2[idx].cpu().numpy().view(np.uint64)
             tc = time.perf_counter()
-            want = o.pairing_batch(h1, h2, nthreads=cores)
-            tcpu = time.perf_counter() - tc
+            want = o.pairing_batch(h1, h2, nthreads=host_cores)
+            t_all = time.perf_counter() - tc
             got = out_gt[idx].cpu().numpy().view(np.uint64)
             parity = bool(np.array_equal(got, want))
-            cpu = {"value": ns / tcpu, "unit": "pairings/s", "cores": cores, "kind": "port",
-                   "sample": "%d of rank 0's %d pairs (every %d-th), CPU restatement oracle/, %d threads" % (ns, n, n // ns, cores)}
+            n1 = min(512, ns)
+            tc = time.perf_counter()
+            one = o.pairing_batch(h1[:n1], h2[:n1], nthreads=1)
+            t_one = time.perf_counter() - tc
+            n_slow = min(64, ns)
+            tc = time.perf_counter()
+            slow = o.pairing_batch_slow(h1[:n_slow], h2[:n_slow], nthreads=1)
+            t_slow = time.perf_counter() - tc
+            parity = parity and bool(np.array_equal(one, want[:n1])) and bool(np.array_equal(slow, want[:n_slow]))
+            cpu = {"value": ns / t_all, "unit": "pairings/s", "cores": host_cores, "kind": "port", "host_cores": host_cores,
+                   "single_thread": {"value": n1 / t_one, "unit": "pairings/s", "cores": 1, "sample": "first %d pairs of the sample" % n1},
+                   "reference_faithful_slow_mode": {
+                       "value": n_slow / t_slow, "unit": "pairings/s", "cores": 1,
+                       "what": "the same restatement built with -DORC_SLOW: canonical integers, 768-bit schoolbook product + long "
+                               "division per Fp::mul as in the reference's src/fp.rs:416-434, Fermat inversions, no Montgomery form; "
+                               "a restatement, NOT the Rust crate (which cannot be built here and has no pairing)",
+                       "sample": "first %d pairs of the sample" % n_slow},
+                   "sample": "%d of rank 0's %d pairs (every %d-th), CPU restatement oracle/, %d threads = every host core" % (ns, n, n // ns, host_cores)}
+        collective = ("1 RCCL all-reduce(MIN) of the AND flag over %d ranks" % ranks) if ranks > 1 else "one rank: no collective"
+        roof = {"bound": "valu-int (neither hbm nor mfma: 384-bit modular arithmetic, >7000 MAC/B)",
+                "achieved": achieved / 1e12, "peak": PEAK_MACS / 1e12, "unit": "T u32-MAC/s",
+                "frac": achieved / PEAK_MACS, "traffic": traffic, "traffic_source": traffic_src,
+                "peak_clock_ghz": NOMINAL_GHZ, "sustained_clock_ghz": sustained_ghz,
+                "frac_at_sustained_clock": (achieved / (LANES_PER_CLK * sustained_ghz * 1e9)) if sustained_ghz else None,
+                "kernel_ms": kern_ms, "algorithmic_macs_per_pairing": MACS_PER_PAIRING,
+                "phases": {
+                    "miller_loop": {"ms": ml_ms, "frac": phase(FPMUL_MILLER, ml_ms), "fp_mul_equivalents": FPMUL_MILLER,
+                                    "kernels": "k_prep_lines + k_coop<30,4> (miller1), Gt-less: Miller value to wire"},
+                    "final_exponentiation": {"ms": fe_ms, "frac": phase(FPMUL_FEXP, fe_ms), "fp_mul_equivalents": FPMUL_FEXP,
+                                             "kernels": "k_coop<24,34> (fexp_a, fexp_c0..5), k_batch_inv, k_ksq, k_kdec_a, k_kdec_b"}},
+                "launch": "one pass over the resident batch = phase A per 2^16-check chunk on two overlapped HIP streams (k_prep_lines, k_coop "
+                          "miller, k_coop fexp_a), ONE k_batch_inv, then the phase C plan over the whole shard: six step programs "
+                          "alternating with five compressed squaring runs (k_ksq) and their decompression (k_kdec_a, k_batch_inv, "
+                          "k_kdec_b); kernel_ms is that pass timed with HIP events on the launching stream; the per-kernel split is in "
+                          "profiles/r02/"}
         line = {
             "metric": "BLS12-381 pairings/s on 2^20 random (G1,G2) pairs; bit-exact Gt vs ref (CPU oracle: the reference's pairings.rs is empty)",
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "batch of %d random (G1,G2) pairs (BASELINE config 3) sharded over %d GPU(s): fused Miller loop + final exponentiation, Gt + identity flags out, 1 RCCL all-reduce(MIN) of the AND flag" % (global_pairs, world),
-                       "pairs_per_gpu": n, "global_pairs": global_pairs, "kernel_family": args.kernel, "all_ok_flag": all_ok,
-                       "gt_sample_bit_exact": parity},
-            "roofline": {"bound": "valu-int (neither hbm nor mfma: 384-bit modular arithmetic, >7000 MAC/B)",
-                         "achieved": achieved / 1e12, "peak": PEAK_MACS / 1e12, "unit": "T u32-MAC/s",
-                         "frac": achieved / PEAK_MACS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "algorithmic_macs_per_pairing": MACS_PER_PAIRING,
-                         "launch": "one pass over the resident batch = phase A per 2^16-check chunk on two overlapped HIP streams (k_prep_lines, k_coop miller, k_coop fexp_a), ONE k_batch_inv and ONE k_coop fexp_c launch over the whole shard; kernel_ms is that pass timed with HIP events on the launching stream (profiles/r01/v18_pass_timeline.txt)"},
+            "config": {"workload": "batch of %d random (G1,G2) pairs (BASELINE config 3) sharded over %d GPU(s): fused Miller loop + final "
+                                   "exponentiation, Gt + identity flags out; %s" % (global_pairs, world, collective),
+                       "pairs_per_gpu": n, "global_pairs": global_pairs, "ranks": ranks, "kernel_family": args.kernel,
+                       "shared_gpu_rehearsal": shared_gpu, "collective_backend": (backend if ranks > 1 else None),
+                       "all_ok_flag": all_ok, "gt_sample_bit_exact": parity},
+            "roofline": roof,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -216,8 +216,14 @@ int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1,
 int zkp_time_pairing_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out_gt, int reps,
                          float* avg_ms);
 
+/* measurement helper used by bench.py: a one-wavefront clock probe queued on `stream`; d_out (device, two u64) receives
+ * the shader-clock ticks and the wall-clock ticks of about spin_us microseconds, *wall_khz the wall clock's rate.
+ * Queued on a second stream beside a running pass it reports the clock the chip sustains under that load. */
+int zkp_clock_probe_dev(zkp_ctx* ctx, void* stream, unsigned spin_us, void* d_out, int* wall_khz);
+
 /* diagnostic: time one synthetic step program of the cooperative interpreter (which: 0 T=1, 1 T=3,
- * 2 T=3+epilogue, 3 T=6, 4 T=12, 5 LIN; 400 iterations each) over n checks; used by tools/ only. */
+ * 2 T=3+epilogue, 3 T=6, 4 T=12, 5 LIN, 6 / 7 cyclotomic squaring without / with companion slots, 8 spill + fill;
+ * 9: 400 compressed squarings of k_ksq) over n checks, on ctx's own stream with its own events; used by tools/ only. */
 int zkp_time_coop_step(zkp_ctx* ctx, int which, size_t n, float* ms);
 
 #ifdef __cplusplus

@@ -14,6 +14,16 @@
 
 #include "orc_constants.h"
 
+/* ORC_SLOW: the "reference-faithful slow mode" of SURVEY.md 8(d) / BASELINE.md 3 - a second build of this file
+ * (oracle/_build/liborc_slow.so) in which Fp works the way the reference's host path does (src/fp.rs:352-434): canonical
+ * integers, a full 768-bit schoolbook product followed by a long division by p, no Montgomery form anywhere.  Same
+ * exported API, same results; only bench.py's cpu_baseline leg times it (on a small sample), labelled as a restatement. */
+#ifdef ORC_SLOW
+#define KONST(name) ORC_C_##name
+#else
+#define KONST(name) ORC_M_##name
+#endif
+
 typedef unsigned __int128 u128;
 typedef struct { uint64_t l[6]; } fp;
 typedef struct { fp c0, c1; } fp2;
@@ -81,6 +91,61 @@ static inline fp fp_sub(const fp* a, const fp* b) {
 
 static inline fp fp_dbl(const fp* a) { return fp_add(a, a); }
 
+#ifdef ORC_SLOW
+/* (a * b) % p the long way: 6 x 6 schoolbook product (12 limbs), then Knuth's Algorithm D (TAOCP 4.3.1) dividing the
+ * 12-limb product by the 6-limb modulus - the shape of num-bigint's BigUint `*` and `%` in the reference's Fp::mul
+ * (src/fp.rs:416-434), minus its heap allocations. */
+static fp fp_mul(const fp* a, const fp* b) {
+    uint64_t t[13] = {0};
+    for (int i = 0; i < 6; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 6; j++) {
+            u128 s = (u128)a->l[i] * b->l[j] + t[i + j] + carry;
+            t[i + j] = (uint64_t)s;
+            carry = (uint64_t)(s >> 64);
+        }
+        t[i + 6] = carry;
+    }
+    /* normalise: p has 381 bits, shift both by 3 so that the divisor's top bit is set */
+    uint64_t v[6], u[13];
+    for (int i = 5; i >= 0; i--) v[i] = (ORC_P[i] << 3) | (i ? ORC_P[i - 1] >> 61 : 0);
+    u[12] = t[11] >> 61;
+    for (int i = 11; i >= 0; i--) u[i] = (t[i] << 3) | (i ? t[i - 1] >> 61 : 0);
+    for (int j = 6; j >= 0; j--) {
+        /* estimate the quotient digit from the top two limbs of the running remainder */
+        u128 num = ((u128)u[j + 6] << 64) | u[j + 5];
+        u128 qhat = num / v[5], rhat = num % v[5];
+        while (qhat >> 64 || (uint64_t)qhat * (u128)v[4] > ((rhat << 64) | u[j + 4])) {
+            qhat--;
+            rhat += v[5];
+            if (rhat >> 64) break;
+        }
+        /* multiply and subtract */
+        uint64_t borrow = 0, carry = 0;
+        for (int i = 0; i < 6; i++) {
+            u128 p = (u128)(uint64_t)qhat * v[i] + carry;
+            carry = (uint64_t)(p >> 64);
+            u128 d = (u128)u[i + j] - (uint64_t)p - borrow;
+            u[i + j] = (uint64_t)d;
+            borrow = (uint64_t)(d >> 64) & 1;
+        }
+        u128 d = (u128)u[j + 6] - carry - borrow;
+        u[j + 6] = (uint64_t)d;
+        if ((uint64_t)(d >> 64) & 1) { /* the estimate was one too large: add the divisor back */
+            uint64_t c = 0;
+            for (int i = 0; i < 6; i++) {
+                u128 s2 = (u128)u[i + j] + v[i] + c;
+                u[i + j] = (uint64_t)s2;
+                c = (uint64_t)(s2 >> 64);
+            }
+            u[j + 6] += c;
+        }
+    }
+    fp r;
+    for (int i = 0; i < 6; i++) r.l[i] = (u[i] >> 3) | (u[i + 1] << 61);
+    return r;
+}
+#else
 /* Montgomery product a*b*R^-1 mod p (CIOS, 64-bit limbs).  The reference's host Fp::mul
  * (src/fp.rs:416-434) is BigUint (a*b) % p on canonical values; with both operands in Montgomery
  * form this computes the Montgomery form of exactly that value. */
@@ -114,14 +179,21 @@ static fp fp_mul(const fp* a, const fp* b) {
     return r;
 }
 
+#endif
 static inline fp fp_sqr(const fp* a) { return fp_mul(a, a); } /* src/fp.rs:453-455 */
 
+#ifdef ORC_SLOW
+static inline fp fp_to_mont(const fp* a) { return *a; }     /* canonical integers all the way */
+static inline fp fp_from_mont(const fp* a) { return *a; }
+static inline fp fp_one(void) { fp r = {{1, 0, 0, 0, 0, 0}}; return r; }
+#else
 static inline fp fp_to_mont(const fp* a) { return fp_mul(a, (const fp*)ORC_R2); }
 static inline fp fp_from_mont(const fp* a) {
     fp one = {{1, 0, 0, 0, 0, 0}};
     return fp_mul(a, &one);
 }
 static inline fp fp_one(void) { return fp_from_arr(ORC_R); }
+#endif
 static inline fp fp_zero(void) { fp r; memset(&r, 0, sizeof r); return r; }
 
 /* square-and-multiply over all 384 exponent bits, MSB first -- reference src/fp.rs:264-276 */
@@ -329,7 +401,7 @@ static int fp6_inv(const fp6* a, fp6* out) {
  * The reference's Fp6::frobenius_map (src/fp6.rs:142-176) uses other constants and is not this map
  * (SURVEY F3); see fp6_frob_refcompat below. */
 static fp6 fp6_frob(const fp6* a) {
-    fp2 k1 = fp2_const(ORC_M_FROB6_C1_0, ORC_M_FROB6_C1_1), k2 = fp2_const(ORC_M_FROB6_C2_0, ORC_M_FROB6_C2_1);
+    fp2 k1 = fp2_const(KONST(FROB6_C1_0), KONST(FROB6_C1_1)), k2 = fp2_const(KONST(FROB6_C2_0), KONST(FROB6_C2_1));
     fp6 r;
     fp2 t;
     r.c0 = fp2_conj(&a->c0);
@@ -343,8 +415,8 @@ static fp6 fp6_frob(const fp6* a) {
 static fp6 fp6_frob_refcompat(const fp6* a) {
     fp z = fp_zero();
     fp2 k1, k2, t;
-    k1.c0 = fp_from_arr(ORC_M_REF_FROB6_C1); k1.c1 = z;
-    k2.c0 = fp_from_arr(ORC_M_REF_FROB6_C2); k2.c1 = z;
+    k1.c0 = fp_from_arr(KONST(REF_FROB6_C1)); k1.c1 = z;
+    k2.c0 = fp_from_arr(KONST(REF_FROB6_C2)); k2.c1 = z;
     fp6 r;
     r.c0 = fp2_conj(&a->c0);
     t = fp2_conj(&a->c1);
@@ -415,7 +487,7 @@ static int fp12_inv(const fp12* a, fp12* out) {
 /* TRUE Frobenius.  Shape of src/fp12.rs:143-170 (c1 scaled by gamma = xi^((p-1)/6), constant
  * verified equal to the reference's) on top of the TRUE Fp6 map. */
 static fp12 fp12_frob(const fp12* a) {
-    fp2 g = fp2_const(ORC_M_FROB12_C1_0, ORC_M_FROB12_C1_1);
+    fp2 g = fp2_const(KONST(FROB12_C1_0), KONST(FROB12_C1_1));
     fp12 r;
     r.c0 = fp6_frob(&a->c0);
     fp6 t = fp6_frob(&a->c1);
@@ -425,7 +497,7 @@ static fp12 fp12_frob(const fp12* a) {
     return r;
 }
 static fp12 fp12_frob_refcompat(const fp12* a) {
-    fp2 g = fp2_const(ORC_M_FROB12_C1_0, ORC_M_FROB12_C1_1);
+    fp2 g = fp2_const(KONST(FROB12_C1_0), KONST(FROB12_C1_1));
     fp12 r;
     r.c0 = fp6_frob_refcompat(&a->c0);
     fp6 t = fp6_frob_refcompat(&a->c1);
@@ -545,7 +617,7 @@ static g1a g1_mul(const g1a* p, const uint64_t k[4]) {
 }
 static int g1_on_curve(const g1a* p) { /* src/g1.rs:95-101 */
     fp yy = fp_sqr(&p->y), xx = fp_sqr(&p->x), xxx = fp_mul(&xx, &p->x);
-    fp rhs = fp_add(&xxx, (const fp*)ORC_M_B);
+    fp rhs = fp_add(&xxx, (const fp*)KONST(B));
     return fp_eq(&yy, &rhs);
 }
 static int g1_torsion_free(const g1a* p) { /* src/g1.rs:111-115: -[X][X]P == (beta x, y) */
@@ -553,7 +625,7 @@ static int g1_torsion_free(const g1a* p) { /* src/g1.rs:111-115: -[X][X]P == (be
     g1a t = g1_mul(p, k);
     t = g1_mul(&t, k);
     t = g1_neg(&t);
-    fp bx = fp_mul(&p->x, (const fp*)ORC_M_BETA);
+    fp bx = fp_mul(&p->x, (const fp*)KONST(BETA));
     if (t.inf) return 0;
     return fp_eq(&t.x, &bx) && fp_eq(&t.y, &p->y);
 }
@@ -607,12 +679,12 @@ static g2a g2_mul(const g2a* p, const uint64_t k[4]) {                          
 static int g2_on_curve(const g2a* p) { /* src/g2.rs:109-120 */
     fp2 yy = fp2_sqr(&p->y), xx = fp2_sqr(&p->x), xxx = fp2_mul(&xx, &p->x);
     fp2 b;
-    b.c0 = fp_from_arr(ORC_M_B); b.c1 = b.c0;
+    b.c0 = fp_from_arr(KONST(B)); b.c1 = b.c0;
     fp2 rhs = fp2_add(&xxx, &b);
     return fp2_eq(&yy, &rhs);
 }
 static g2a g2_psi(const g2a* p) { /* src/g2.rs:126-164 */
-    fp2 kx = fp2_const(ORC_M_PSI_X_0, ORC_M_PSI_X_1), ky = fp2_const(ORC_M_PSI_Y_0, ORC_M_PSI_Y_1);
+    fp2 kx = fp2_const(KONST(PSI_X_0), KONST(PSI_X_1)), ky = fp2_const(KONST(PSI_Y_0), KONST(PSI_Y_1));
     g2a r;
     fp2 t = fp2_conj(&p->x);
     r.x = fp2_mul(&t, &kx);
@@ -912,9 +984,9 @@ void orc_fp12_frobenius_map_refcompat(const uint64_t a[72], uint64_t out[72]) { 
 void orc_fp12_cyclotomic_square(const uint64_t a[72], uint64_t out[72]) { fp12 x = fp12_load(a), r = fp12_cyclotomic_square(&x); fp12_store(out, &r); }
 void orc_fp12_pow_u64(const uint64_t a[72], uint64_t e, uint64_t out[72]) { fp12 x = fp12_load(a), r = fp12_pow_u64(&x, e); fp12_store(out, &r); }
 
-void orc_g1_generator(uint64_t out[12]) { g1a g; g.x = fp_from_arr(ORC_M_G1_X); g.y = fp_from_arr(ORC_M_G1_Y); g.inf = 0; g1_store(out, NULL, &g); }
+void orc_g1_generator(uint64_t out[12]) { g1a g; g.x = fp_from_arr(KONST(G1_X)); g.y = fp_from_arr(KONST(G1_Y)); g.inf = 0; g1_store(out, NULL, &g); }
 void orc_g2_generator(uint64_t out[24]) {
-    g2a g; g.x = fp2_const(ORC_M_G2_X0, ORC_M_G2_X1); g.y = fp2_const(ORC_M_G2_Y0, ORC_M_G2_Y1); g.inf = 0; g2_store(out, NULL, &g);
+    g2a g; g.x = fp2_const(KONST(G2_X0), KONST(G2_X1)); g.y = fp2_const(KONST(G2_Y0), KONST(G2_Y1)); g.inf = 0; g2_store(out, NULL, &g);
 }
 void orc_g1_double(const uint64_t p[12], uint8_t inf, uint64_t out[12], uint8_t* out_inf) { g1a x = g1_load(p, inf), r = g1_double(&x); g1_store(out, out_inf, &r); }
 void orc_g1_add(const uint64_t p[12], uint8_t pinf, const uint64_t q[12], uint8_t qinf, uint64_t out[12], uint8_t* out_inf) {

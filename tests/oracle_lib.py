@@ -16,7 +16,8 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 
 def build(force=False):
     src = [os.path.join(ORACLE_DIR, f) for f in ("bls12_381_oracle.c", "bls12_381_oracle.h", "orc_constants.h")]
-    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
+    if force or not os.path.exists(LIB_PATH) or not os.path.exists(os.path.join(ORACLE_DIR, "_build", "liborc_slow.so")) or \
+            any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
         subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
@@ -264,6 +265,27 @@ def pairing_batch(g1, g2, inf1=None, inf2=None, nthreads=1):
     inf1, inf2 = _infs(inf1, n), _infs(inf2, n)
     out = np.zeros(72 * n, dtype=np.uint64)
     lib().orc_pairing_batch_mt(_p(g1), _p(g2), _b(inf1), _b(inf2), ctypes.c_size_t(n), _p(out), ctypes.c_int(nthreads))
+    return out.reshape(n, 72)
+
+
+SLOW_LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liborc_slow.so")
+_slow = None
+
+
+def pairing_batch_slow(g1, g2, nthreads=1):
+    """the same pairings through the reference-faithful slow build (-DORC_SLOW: canonical integers, schoolbook product +
+    long division per Fp::mul as in the reference's src/fp.rs:416-434); only for bench.py's cpu_baseline leg and its test"""
+    global _slow
+    if _slow is None:
+        build()
+        if not os.path.exists(SLOW_LIB_PATH):
+            subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+        _slow = ctypes.CDLL(SLOW_LIB_PATH)
+    g1, g2 = _arr(g1), _arr(g2)
+    n = g1.size // 12
+    assert g2.size == 24 * n
+    out = np.zeros(72 * n, dtype=np.uint64)
+    _slow.orc_pairing_batch_mt(_p(g1), _p(g2), None, None, ctypes.c_size_t(n), _p(out), ctypes.c_int(nthreads))
     return out.reshape(n, 72)
 
 

@@ -1,0 +1,166 @@
+"""BASELINE.json configs 3, 4 and 5 at their stated sizes on one MI355X (run with -m gpu), through the C ABI.
+
+At 2^20 elements the CPU oracle cannot check everything in seconds, so every test combines
+  * a size-independent property that covers EVERY element (cancelling 2-pair checks, flags known by construction,
+    statuses known by construction, one kernel family against the other),
+  * a seeded sample compared bit for bit with the oracle.
+tools/soak.py runs the same checks stand-alone and prints the digests kept under profiles/."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import bls12_381_model as m
+import oracle_lib as o
+
+pytestmark = pytest.mark.gpu
+NTHREADS = 16
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from zkvm_pairings_amd import PairingEngine
+    e = PairingEngine(0)
+    yield e
+    e.close()
+
+
+def test_config3_full_batch_2p20(eng):
+    """config 3 on one GPU: 2^20 random (G1,G2) pairs through pairing() + the Gt::identity() check (the bench step)."""
+    import torch
+    from zkvm_pairings_amd import configs
+    r = configs.run_config3(eng, 1 << 20, sample=1 << 12, prefix=1 << 16)
+    assert r["flags_all_zero"] and r["all_ok"] == 0                   # random pairings are never the identity
+    assert r["cancel_all_one"] and r["cancel_all_ok"] == 1            # e(P,Q) e(-P,Q) == 1 for EVERY element
+    assert r["infinity_all_one"]                                      # every infinity flag set: AND flag true
+    assert r["families_sha256_equal"], (r["sha256_prefix_coop"], r["sha256_prefix_thread"])
+    g1, g2, got = r["sample_g1"], r["sample_g2"], r["sample_gt"]
+    want = o.pairing_batch(g1, g2, nthreads=NTHREADS)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
+    assert np.array_equal(got, want)
+    torch.cuda.empty_cache()
+
+
+def test_config4_groth16_checks_2p18(eng):
+    """config 4: 2^18 three-pair checks with one shared final exponentiation each; a3 solved so that the product is one,
+    a seeded 1/1024 of the checks perturbed: every flag equals the constructed expectation, 64 vs the oracle."""
+    from zkvm_pairings_amd import configs
+    r = configs.run_config4(eng, 1 << 18)
+    assert r["n_bad"] > 100 and r["flags_equal_expectation"] and r["all_ok"] == 0
+    assert r["good_prefix_all_ok"] == 1
+    g1, g2 = r["sample_g1"], r["sample_g2"]
+    assert np.array_equal(r["sample_ok"], o.pairing_check_batch(g1, g2, 64, 3))
+    assert np.array_equal(r["sample_ok"], r["sample_expect"])
+
+
+def test_config5_raw_points_2p20(eng):
+    """config 5 on one GPU: 2^20 uncompressed G1 and G2 byte strings -> decode -> is_valid with seeded fractions of
+    off-curve, wrong-subgroup, non-canonical and infinity encodings; then the pairing check on the valid ones."""
+    from zkvm_pairings_amd import configs
+    r = configs.run_config5(eng, 1 << 20)
+    for which in ("g1", "g2"):
+        assert r[which + "_decode_status_equal"] and r[which + "_valid_status_equal"], which
+        assert min(r[which + "_class_counts"].values()) > 50, r[which + "_class_counts"]
+        pts, inf, st = r[which + "_sample"]
+        fn = o.g1_is_valid if which == "g1" else o.g2_is_valid
+        assert [fn(p, int(i)) for p, i in zip(pts, inf)] == st.tolist()
+    assert r["pairing_checks_all_one"]
+
+
+def test_pairing_over_several_contexts_from_c(tmp_path):
+    """integration/c/zkp_multi.c: zkp_pairing_batch_multi / zkp_pairing_check_batch_multi with three contexts (all on
+    device 0 of a one-GPU box) against the single-context calls, from plain C."""
+    exe = str(tmp_path / "zkp_multi")
+    libdir = os.path.join(ROOT, "zkvm_pairings_amd")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "integration", "c", "zkp_multi.c"),
+                           "-L", libdir, "-lzkp_pairings", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe, "3", "1500"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    assert "C ABI multi-context ok" in out.stdout
+    out = subprocess.run([exe, "2", "5"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+
+
+def test_multi_context_entry_points_from_python(eng):
+    from zkvm_pairings_amd import PairingEngine, multi, synthetic
+    others = [PairingEngine(0), PairingEngine(0)]
+    try:
+        n = 777
+        g1, g2, _, _ = synthetic.random_pairs(eng, n, seed=99)
+        inf1 = np.zeros(n, dtype=np.uint8)
+        inf1[[0, 300, 776]] = 1
+        gt, ok, allok = multi.pairing_multi([eng] + others, g1, g2, inf1, None)
+        assert np.array_equal(gt, eng.pairing(g1, g2, inf1, None))
+        assert np.array_equal(ok, inf1) and not allok
+        ok3, all3 = multi.pairing_check_multi([eng] + others, g1[:774], g2[:774], 3)
+        ok1, all1 = eng.pairing_check(g1[:774], g2[:774], 3)
+        assert np.array_equal(ok3, ok1) and all3 == all1
+    finally:
+        for e in others:
+            e.close()
+
+
+def test_dev_calls_on_two_streams_do_not_race(eng):
+    """two back-to-back zkp_pairing_batch_dev calls of ONE context on two different streams: the second waits (event) for
+    the first one's use of the shared workspace; results equal the serial ones."""
+    import torch
+    from zkvm_pairings_amd import synthetic
+    dev = torch.device("cuda", 0)
+    n = 1 << 15
+    a1, a2, _, _ = synthetic.random_pairs(eng, n, seed=5, device_tensors=True)
+    b1, b2, _, _ = synthetic.random_pairs(eng, n, seed=6, device_tensors=True)
+    ref_a, ref_b = eng.pairing(a1, a2), eng.pairing(b1, b2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            got_a = eng.pairing(a1, a2)
+        with torch.cuda.stream(s2):
+            got_b = eng.pairing(b1, b2)
+        torch.cuda.synchronize()
+        assert torch.equal(got_a, ref_a) and torch.equal(got_b, ref_b)
+
+
+def test_validation_mode_on_device_pointers(eng):
+    import torch
+    from zkvm_pairings_amd import synthetic
+    dev = torch.device("cuda", 0)
+    g1, g2, _, _ = synthetic.random_pairs(eng, 64, seed=8, device_tensors=True)
+    eng.set_validate(True)
+    try:
+        eng.pairing(g1, g2)
+        assert eng.take_validation_status() is False
+        bad = g1.clone()
+        bad[5, :6] = torch.from_numpy(o.to_limbs(m.P).view(np.int64)).to(dev)   # x = p: not canonical
+        eng.pairing(bad, g2)
+        assert eng.take_validation_status() is True
+        assert eng.take_validation_status() is False                              # reading clears the word
+    finally:
+        eng.set_validate(False)
+
+
+def test_two_ranks_sharded_check_equals_single_rank(tmp_path):
+    """two torchrun ranks sharing cuda:0 (gloo for the single collective of the path): the sharded AND flag, the
+    sharded product check and bench.py's N = 2 line against the single-rank results"""
+    script = os.path.join(ROOT, "tests", "dist_two_ranks.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", ZKP_BENCH_SHARE_GPU="1", ZKP_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", script], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "TWO RANKS OK" in out.stdout
+    # bench.py's own N = 2 path (contiguous shards of one seeded batch, max-over-ranks timing, the MIN all-reduce)
+    import json
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29518", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pairs", "65536",
+                          "--cpu-sample", "512"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["config"]["pairs_per_gpu"] == 32768
+    assert line["config"]["gt_sample_bit_exact"] is True and "all-reduce(MIN)" in line["config"]["workload"]
+    # and the guard: --gpus must match the number of ranks
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 2 and "WORLD_SIZE" in out.stderr

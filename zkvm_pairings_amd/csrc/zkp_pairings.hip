@@ -113,6 +113,21 @@ __global__ void __launch_bounds__(TPB) k_pairing(const uint64_t* g1, const uint6
 
 __global__ void k_set_int(int* p, int v) { *p = v; }
 
+// one wavefront that watches the shader clock counter (s_memtime) against the constant-rate wall clock (s_memrealtime)
+// for about spin_us microseconds: out[0] = shader clock ticks, out[1] = wall clock ticks.  Launched beside a running
+// pass it reports the clock the chip sustains under that load (bench.py: roofline.frac_at_sustained_clock).
+__global__ void k_clock_probe(unsigned long long* out, unsigned long long wall_ticks) {
+    if (threadIdx.x) return;
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    unsigned long long w1 = w0;
+    while (w1 - w0 < wall_ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        w1 = wall_clock64();
+    }
+    out[0] = clock64() - c0;
+    out[1] = w1 - w0;
+}
+
 // one level of the Fp12 product tree, in place on wire records: buf[c] <- buf[c] * buf[c + h], c < m
 __global__ void __launch_bounds__(TPB) k_fp12_mul_pairs(uint64_t* buf, size_t m, size_t h) {
     size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
@@ -1224,6 +1239,21 @@ int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1,
                             uint64_t* out_gt, uint8_t* ok, int* all_ok) {
     if (n && !out_gt) return ZKP_ERR_ARG;
     return multi_impl(ctxs, n_ctx, g1, g2, inf1, inf2, n, 1, out_gt, ok, all_ok);
+}
+
+// measurement helper: a one-wavefront clock probe on `stream` (asynchronous); d_out receives two u64: shader clock ticks
+// and wall clock ticks over about spin_us microseconds; *wall_khz (host) is the wall clock's rate.
+int zkp_clock_probe_dev(zkp_ctx* c, void* stream, unsigned spin_us, void* d_out, int* wall_khz) {
+    if (!c || !d_out || !wall_khz || spin_us == 0 || spin_us > 1000000u) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    int khz = 0;
+    HIPCHK(c, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+    if (khz <= 0) { c->err = "wall clock rate unknown"; return ZKP_ERR_HIP; }
+    *wall_khz = khz;
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, S(stream), (unsigned long long*)d_out, (unsigned long long)spin_us * (unsigned long long)khz / 1000ull);
+    HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
 }
 
 int zkp_time_coop_step(zkp_ctx* c, int which, size_t n, float* ms) {

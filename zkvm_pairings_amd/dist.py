@@ -25,17 +25,33 @@ def shard_range(n_total, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _host_backend():
+    """gloo (CPU tests, one-GPU rehearsals) reduces host tensors; nccl (= RCCL) reduces device tensors in place"""
+    return dist.get_backend() != "nccl"
+
+
 def and_reduce(flag):
-    """flag: int32 tensor of shape (1,) holding 0/1 on this rank's device -> global AND, in place"""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    """flag: int32 tensor of shape (1,) holding 0/1 on this rank's device -> global AND, in place.
+    One all-reduce(MIN) per call; on a single rank there is nothing to do."""
+    if _active():
+        if flag.is_cuda and _host_backend():
+            h = flag.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MIN)
+            flag.copy_(h)
+        else:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return flag
 
 
 def max_over_ranks(seconds, device):
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if not _active():
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if _host_backend() else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
@@ -55,10 +71,13 @@ def sharded_pairing_check(check_fn, n_checks, device):
 def gather_parts(part):
     """part: (72,) int64/uint64 tensor (this rank's Fp12 Miller product) -> (world, 72) on every rank.
     One all_gather of 576 B per rank (latency bound; xGMI bandwidth is irrelevant)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        parts = [torch.empty_like(part) for _ in range(dist.get_world_size())]
-        dist.all_gather(parts, part.contiguous())
-        return torch.stack(parts)
+    if _active():
+        src = part.contiguous()
+        if src.is_cuda and _host_backend():
+            src = src.cpu()
+        parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, src)
+        return torch.stack(parts).to(part.device)
     return part.reshape(1, 72)
 
 

@@ -20,6 +20,16 @@ def _np(a, cols, dtype=np.uint64):
     return a
 
 
+def _flags(inf, n, name):
+    """optional per-point infinity flags: n bytes"""
+    if inf is None:
+        return None
+    a = np.ascontiguousarray(inf, dtype=np.uint8).reshape(-1)
+    if a.size != n:
+        raise ValueError("%s: %d flags for %d points" % (name, a.size, n))
+    return a
+
+
 def _ptr(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
 
@@ -65,6 +75,13 @@ class PairingEngine:
     def set_validate(self, on):
         self._chk(self._lib.zkp_set_validate(self._h, 1 if on else 0))
 
+    def take_validation_status(self):
+        """validation mode on the device-tensor entry points: True if any such call since the last query saw a field
+        element >= p (synchronises the current torch stream; clears the word)"""
+        bad = ctypes.c_int(0)
+        self._chk(self._lib.zkp_take_validation_status_dev(self._h, self._stream(), ctypes.byref(bad)))
+        return bool(bad.value)
+
     def device_info(self):
         cus, clk = ctypes.c_int(), ctypes.c_int()
         name = ctypes.create_string_buffer(64)
@@ -83,9 +100,9 @@ class PairingEngine:
             return self._pairing_t(g1, g2, inf1, inf2)
         g1, g2 = _np(g1, 12), _np(g2, 24)
         n = g1.shape[0]
-        assert g2.shape[0] == n
-        i1 = None if inf1 is None else _np(inf1, None, np.uint8)
-        i2 = None if inf2 is None else _np(inf2, None, np.uint8)
+        if g2.shape[0] != n:
+            raise ValueError("g1 and g2 hold different numbers of points")
+        i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
         out = np.empty((n, 72), dtype=np.uint64)
         self._chk(self._lib.zkp_pairing_batch(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n, _ptr(out)))
         return out
@@ -96,9 +113,9 @@ class PairingEngine:
             return self._miller_t(g1, g2, k, inf1, inf2)
         g1, g2 = _np(g1, 12), _np(g2, 24)
         n = g1.shape[0]
-        assert g2.shape[0] == n and k > 0 and n % k == 0
-        i1 = None if inf1 is None else _np(inf1, None, np.uint8)
-        i2 = None if inf2 is None else _np(inf2, None, np.uint8)
+        if g2.shape[0] != n or k <= 0 or n % k:
+            raise ValueError("g1 / g2 sizes do not match or are not a multiple of k")
+        i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
         out = np.empty((n // k, 72), dtype=np.uint64)
         self._chk(self._lib.zkp_multi_miller_loop_batch(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n // k, k, _ptr(out)))
         return out
@@ -117,9 +134,9 @@ class PairingEngine:
             return self._check_t(g1, g2, k, inf1, inf2)
         g1, g2 = _np(g1, 12), _np(g2, 24)
         n = g1.shape[0]
-        assert g2.shape[0] == n and k > 0 and n % k == 0
-        i1 = None if inf1 is None else _np(inf1, None, np.uint8)
-        i2 = None if inf2 is None else _np(inf2, None, np.uint8)
+        if g2.shape[0] != n or k <= 0 or n % k:
+            raise ValueError("g1 / g2 sizes do not match or are not a multiple of k")
+        i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
         ok = np.empty(n // k, dtype=np.uint8)
         allok = ctypes.c_int(1)
         self._chk(self._lib.zkp_pairing_check_batch(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n // k, k, _ptr(ok), ctypes.byref(allok)))
@@ -130,16 +147,16 @@ class PairingEngine:
         """multi_miller_loop over ALL pairs of the batch -> (72,) MillerLoopResult"""
         if _is_torch(g1):
             import torch
-            self._t_check(g1, 12), self._t_check(g2, 24)
+            self._t_pairs(g1, g2, inf1, inf2)
             out = torch.empty(72, dtype=g1.dtype, device=g1.device)
             self._chk(self._lib.zkp_miller_product_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), g1.numel() // 12,
                                                        self._tp(out), self._stream()))
             return out
         g1, g2 = _np(g1, 12), _np(g2, 24)
         n = g1.shape[0]
-        assert g2.shape[0] == n
-        i1 = None if inf1 is None else _np(inf1, None, np.uint8)
-        i2 = None if inf2 is None else _np(inf2, None, np.uint8)
+        if g2.shape[0] != n:
+            raise ValueError("g1 and g2 hold different numbers of points")
+        i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
         out = np.empty(72, dtype=np.uint64)
         self._chk(self._lib.zkp_miller_product(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n, _ptr(out)))
         return out
@@ -148,7 +165,7 @@ class PairingEngine:
         """f_0 * f_1 * ... * f_n-1 of (n,72) Fp12 values -> (72,)"""
         if _is_torch(f):
             import torch
-            self._t_check(f, 72)
+            self._t_check(f, 72, "f")
             out = torch.empty(72, dtype=f.dtype, device=f.device)
             self._chk(self._lib.zkp_fp12_product_dev(self._h, self._tp(f), f.numel() // 72, self._tp(out), self._stream()))
             return out
@@ -162,7 +179,7 @@ class PairingEngine:
         Device tensors return (Gt tensor, int32 tensor(1,)) without synchronising."""
         if _is_torch(g1):
             import torch
-            self._t_check(g1, 12), self._t_check(g2, 24)
+            self._t_pairs(g1, g2, inf1, inf2)
             gt = torch.empty(72, dtype=g1.dtype, device=g1.device)
             one = torch.empty(1, dtype=torch.int32, device=g1.device)
             self._chk(self._lib.zkp_pairing_product_check_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), g1.numel() // 12,
@@ -170,9 +187,9 @@ class PairingEngine:
             return gt, one
         g1, g2 = _np(g1, 12), _np(g2, 24)
         n = g1.shape[0]
-        assert g2.shape[0] == n
-        i1 = None if inf1 is None else _np(inf1, None, np.uint8)
-        i2 = None if inf2 is None else _np(inf2, None, np.uint8)
+        if g2.shape[0] != n:
+            raise ValueError("g1 and g2 hold different numbers of points")
+        i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
         gt = np.empty(72, dtype=np.uint64)
         one = ctypes.c_int(0)
         self._chk(self._lib.zkp_pairing_product_check(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n, _ptr(gt), ctypes.byref(one)))
@@ -182,7 +199,7 @@ class PairingEngine:
         if _is_torch(g1):
             return self._valid_t(g1, inf, 1)
         g1 = _np(g1, 12)
-        i = None if inf is None else _np(inf, None, np.uint8)
+        i = _flags(inf, g1.shape[0], "inf")
         st = np.empty(g1.shape[0], dtype=np.uint8)
         self._chk(self._lib.zkp_g1_is_valid_batch(self._h, _ptr(g1), _ptr(i), g1.shape[0], _ptr(st)))
         return st
@@ -191,7 +208,7 @@ class PairingEngine:
         if _is_torch(g2):
             return self._valid_t(g2, inf, 2)
         g2 = _np(g2, 24)
-        i = None if inf is None else _np(inf, None, np.uint8)
+        i = _flags(inf, g2.shape[0], "inf")
         st = np.empty(g2.shape[0], dtype=np.uint8)
         self._chk(self._lib.zkp_g2_is_valid_batch(self._h, _ptr(g2), _ptr(i), g2.shape[0], _ptr(st)))
         return st
@@ -204,7 +221,8 @@ class PairingEngine:
         base = _np(base, 12)
         n = sc.shape[0]
         stride = 0 if base.shape[0] == 1 and n != 1 else 12
-        assert stride == 0 or base.shape[0] == n
+        if stride and base.shape[0] != n:
+            raise ValueError("base points and scalars differ in number")
         out, oi = np.empty((n, 12), dtype=np.uint64), np.empty(n, dtype=np.uint8)
         self._chk(self._lib.zkp_g1_mul_batch(self._h, _ptr(base), stride, _ptr(sc), n, _ptr(out), _ptr(oi)))
         return out, oi
@@ -216,7 +234,8 @@ class PairingEngine:
         base = _np(base, 24)
         n = sc.shape[0]
         stride = 0 if base.shape[0] == 1 and n != 1 else 24
-        assert stride == 0 or base.shape[0] == n
+        if stride and base.shape[0] != n:
+            raise ValueError("base points and scalars differ in number")
         out, oi = np.empty((n, 24), dtype=np.uint64), np.empty(n, dtype=np.uint8)
         self._chk(self._lib.zkp_g2_mul_batch(self._h, _ptr(base), stride, _ptr(sc), n, _ptr(out), _ptr(oi)))
         return out, oi
@@ -225,7 +244,8 @@ class PairingEngine:
         """uncompressed big-endian bytes -> (points, inf, status); which = 1 (G1, 96 B) or 2 (G2, 192 B)"""
         size = 96 if which == 1 else 192
         buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
-        assert buf.size % size == 0
+        if buf.size % size:
+            raise ValueError("byte string is not a multiple of %d bytes" % size)
         n = buf.size // size
         pts = np.empty((n, size // 8), dtype=np.uint64)
         inf, st = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8)
@@ -237,7 +257,7 @@ class PairingEngine:
         cols = 12 if which == 1 else 24
         pts = _np(pts, cols)
         n = pts.shape[0]
-        i = None if inf is None else _np(inf, None, np.uint8)
+        i = _flags(inf, n, "inf")
         out = np.empty(n * cols * 8, dtype=np.uint8)
         fn = self._lib.zkp_g1_encode_batch if which == 1 else self._lib.zkp_g2_encode_batch
         self._chk(fn(self._h, _ptr(pts), _ptr(i), n, _ptr(out)))
@@ -271,13 +291,37 @@ class PairingEngine:
         return out
 
     # ------------------------------------------------------------------ torch (device-resident) API
-    def _t_check(self, t, cols):
+    def _t_check(self, t, cols, name="tensor", rows=None, dtypes=None):
+        """every tensor handed to a *_dev entry point: on this engine's GPU, contiguous, 64-bit words (or bytes), and
+        large enough - a wrong-sized or CPU tensor would otherwise become an out-of-bounds access in HBM"""
         import torch
-        assert t.is_cuda and t.device.index == self.device and t.is_contiguous(), "tensor must be contiguous on cuda:%d" % self.device
-        assert t.dtype in (torch.int64, torch.uint64, torch.uint8)
-        if cols is not None:
-            assert t.numel() % cols == 0
+        if not _is_torch(t):
+            raise TypeError("%s: expected a torch tensor" % name)
+        if not t.is_cuda or t.device.index != self.device:
+            raise ValueError("%s must live on cuda:%d" % (name, self.device))
+        if not t.is_contiguous():
+            raise ValueError("%s must be contiguous" % name)
+        if t.dtype not in (dtypes or (torch.int64, torch.uint64)):
+            raise ValueError("%s has dtype %s" % (name, t.dtype))
+        if cols is not None and t.numel() % cols:
+            raise ValueError("%s: %d elements is not a multiple of %d" % (name, t.numel(), cols))
+        if rows is not None and t.numel() < rows * (cols or 1):
+            raise ValueError("%s: %d elements, %d needed" % (name, t.numel(), rows * (cols or 1)))
         return t
+
+    def _t_bytes(self, t, n, name):
+        import torch
+        return None if t is None else self._t_check(t, None, name, rows=n, dtypes=(torch.uint8,))
+
+    def _t_pairs(self, g1, g2, inf1, inf2, k=1):
+        self._t_check(g1, 12, "g1"), self._t_check(g2, 24, "g2")
+        n = g1.numel() // 12
+        if g2.numel() // 24 != n:
+            raise ValueError("g1 holds %d points, g2 %d" % (n, g2.numel() // 24))
+        if k <= 0 or n % k:
+            raise ValueError("%d pairs is not a positive multiple of k = %d" % (n, k))
+        self._t_bytes(inf1, n, "inf1"), self._t_bytes(inf2, n, "inf2")
+        return n
 
     @staticmethod
     def _tp(t):
@@ -290,51 +334,53 @@ class PairingEngine:
 
     def _pairing_t(self, g1, g2, inf1, inf2, out=None):
         import torch
-        self._t_check(g1, 12), self._t_check(g2, 24)
-        n = g1.numel() // 12
+        n = self._t_pairs(g1, g2, inf1, inf2)
         if out is None:
             out = torch.empty((n, 72), dtype=g1.dtype, device=g1.device)
+        self._t_check(out, 72, "out", rows=n)
         self._chk(self._lib.zkp_pairing_batch_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), n, self._tp(out), self._stream()))
         return out
 
     def _miller_t(self, g1, g2, k, inf1, inf2):
         import torch
-        self._t_check(g1, 12), self._t_check(g2, 24)
-        n = g1.numel() // 12
-        assert n % k == 0
+        n = self._t_pairs(g1, g2, inf1, inf2, k)
         out = torch.empty((n // k, 72), dtype=g1.dtype, device=g1.device)
         self._chk(self._lib.zkp_multi_miller_loop_batch_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), n // k, k, self._tp(out), self._stream()))
         return out
 
     def _fexp_t(self, f):
         import torch
-        self._t_check(f, 72)
+        self._t_check(f, 72, "f")
         out = torch.empty_like(f)
         self._chk(self._lib.zkp_final_exponentiation_batch_dev(self._h, self._tp(f), f.numel() // 72, self._tp(out), self._stream()))
         return out
 
     def _check_t(self, g1, g2, k, inf1, inf2):
         import torch
-        self._t_check(g1, 12), self._t_check(g2, 24)
-        n = g1.numel() // 12
-        assert n % k == 0
+        n = self._t_pairs(g1, g2, inf1, inf2, k)
         ok = torch.empty(n // k, dtype=torch.uint8, device=g1.device)
         allok = torch.empty(1, dtype=torch.int32, device=g1.device)
         self._chk(self._lib.zkp_pairing_check_batch_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), n // k, k, self._tp(ok), self._tp(allok), self._stream()))
         return ok, allok
 
     def pairing_gt_check(self, g1, g2, k, out_gt, ok, all_ok, inf1=None, inf2=None):
-        """device tensors only: Gt out + ok bytes + AND flag in one fused pass (bench step)."""
-        self._t_check(g1, 12), self._t_check(g2, 24)
-        n = g1.numel() // 12
+        """device tensors only: Gt out + ok bytes + AND flag in one fused pass (bench step); out_gt / ok / all_ok are each optional"""
+        import torch
+        n = self._t_pairs(g1, g2, inf1, inf2, k)
+        if out_gt is not None:
+            self._t_check(out_gt, 72, "out_gt", rows=n // k)
+        self._t_bytes(ok, n // k, "ok")
+        if all_ok is not None:
+            self._t_check(all_ok, None, "all_ok", rows=1, dtypes=(torch.int32,))
         self._chk(self._lib.zkp_pairing_gt_check_batch_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), n // k, k,
                                                            self._tp(out_gt), self._tp(ok), self._tp(all_ok), self._stream()))
 
     def _valid_t(self, pts, inf, which):
         import torch
         cols = 12 if which == 1 else 24
-        self._t_check(pts, cols)
+        self._t_check(pts, cols, "points")
         n = pts.numel() // cols
+        self._t_bytes(inf, n, "inf")
         st = torch.empty(n, dtype=torch.uint8, device=pts.device)
         fn = self._lib.zkp_g1_is_valid_batch_dev if which == 1 else self._lib.zkp_g2_is_valid_batch_dev
         self._chk(fn(self._h, self._tp(pts), self._tp(inf), n, self._tp(st), self._stream()))
@@ -343,22 +389,34 @@ class PairingEngine:
     def _mul_t(self, base, scalars, which):
         import torch
         cols = 12 if which == 1 else 24
-        self._t_check(scalars, 4)
+        self._t_check(scalars, 4, "scalars")
         n = scalars.numel() // 4
         if not _is_torch(base):
             base = torch.from_numpy(np.ascontiguousarray(base, dtype=np.uint64).view(np.int64)).to(scalars.device)
         base = base.contiguous().view(-1)
-        self._t_check(base, cols)
+        self._t_check(base, cols, "base")
         stride = 0 if base.numel() == cols and n != 1 else cols
+        if stride and base.numel() != n * cols:
+            raise ValueError("base holds %d points, %d scalars given" % (base.numel() // cols, n))
         out = torch.empty((n, cols), dtype=scalars.dtype, device=scalars.device)
         oi = torch.empty(n, dtype=torch.uint8, device=scalars.device)
         fn = self._lib.zkp_g1_mul_batch_dev if which == 1 else self._lib.zkp_g2_mul_batch_dev
         self._chk(fn(self._h, self._tp(base), stride, self._tp(scalars), n, self._tp(out), self._tp(oi), self._stream()))
         return out, oi
 
+    def clock_probe(self, stream, spin_us=20000):
+        """queue the one-wavefront clock probe on `stream` (a torch.cuda.Stream); -> (tensor of two int64: shader-clock
+        ticks, wall-clock ticks; valid once the stream has drained, wall clock rate in kHz)"""
+        import torch
+        out = torch.zeros(2, dtype=torch.int64, device=torch.device("cuda", self.device))
+        khz = ctypes.c_int(0)
+        self._chk(self._lib.zkp_clock_probe_dev(self._h, ctypes.c_void_p(stream.cuda_stream), int(spin_us), self._tp(out), ctypes.byref(khz)))
+        return out, khz.value
+
     def time_pairing(self, g1, g2, out, reps):
         """avg ms per launch of the fused pairing kernel, HIP events on the engine's own stream."""
-        self._t_check(g1, 12), self._t_check(g2, 24), self._t_check(out, 72)
+        n = self._t_pairs(g1, g2, None, None)
+        self._t_check(out, 72, "out", rows=n)
         ms = ctypes.c_float()
         self._chk(self._lib.zkp_time_pairing_dev(self._h, self._tp(g1), self._tp(g2), g1.numel() // 12, self._tp(out), int(reps), ctypes.byref(ms)))
         return ms.value

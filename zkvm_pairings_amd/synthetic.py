@@ -32,12 +32,45 @@ def splitmix64(seed, count, offset=0):
         return z ^ (z >> np.uint64(31))
 
 
+_R_LIMBS = np.array([(R_ORDER >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+_ATTEMPTS = 16
+
+
+def _below_r(w):
+    """(n,4) little-endian uint64 values: 0 < value < r, elementwise"""
+    lt = np.zeros(w.shape[0], dtype=bool)
+    eq = np.ones(w.shape[0], dtype=bool)
+    for i in (3, 2, 1, 0):
+        lt |= eq & (w[:, i] < _R_LIMBS[i])
+        eq &= w[:, i] == _R_LIMBS[i]
+    return lt & (w != 0).any(axis=1)
+
+
 def scalars(seed, n, offset=0):
-    """(n,4) uint64 scalars, uniform in [1, 2^254) (< r): 4 stream words each, top word masked."""
-    w = splitmix64(seed, 4 * n, 4 * offset).reshape(n, 4).copy()
-    w[:, 3] &= np.uint64((1 << 62) - 1)
-    w[:, 0] |= np.uint64(1)
-    return w
+    """(n,4) uint64 scalars, uniform in [1, r) by rejection: scalar i takes the first of its (at most 16)
+    255-bit candidates that lies in [1, r); candidate a of scalar i is words 4 (16 i + a) .. + 3 of the SplitMix64 stream,
+    so any slice of the sequence can be generated on its own (offset).  A candidate is rejected with probability 0.095."""
+    out = np.zeros((n, 4), dtype=np.uint64)
+    step = 1 << 15                                    # small blocks: the temporaries stay cache resident
+    lane = np.arange(1, 5, dtype=np.uint64)[None, :]
+    for lo in range(0, n, step):
+        todo = np.arange(lo, min(n, lo + step), dtype=np.int64)
+        for a in range(_ATTEMPTS):
+            if todo.size == 0:
+                break
+            with np.errstate(over="ignore"):
+                first = (np.uint64(offset) + todo.astype(np.uint64)) * np.uint64(4 * _ATTEMPTS) + np.uint64(4 * a)
+                z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + (first[:, None] + lane) * np.uint64(0x9E3779B97F4A7C15)
+                z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                w = z ^ (z >> np.uint64(31))
+            w[:, 3] &= np.uint64((1 << 63) - 1)
+            good = _below_r(w)
+            out[todo[good]] = w[good]
+            todo = todo[~good]
+        if todo.size:       # probability 4e-17 per scalar
+            out[todo] = int_to_scalar(1)
+    return out
 
 
 def scalar_to_int(row):
