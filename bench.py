@@ -31,6 +31,30 @@ NOMINAL_GHZ = 2.4
 PEAK_MACS = LANES_PER_CLK * NOMINAL_GHZ * 1e9
 
 
+def usable_cores():
+    """threads the CPU leg may use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box hands one GPU's job
+    a share of the host - 16 cores - while os.cpu_count() still reports every core of the machine)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(parts[0]) // int(parts[1])))
+            elif int(parts[0]) > 0:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    n = min(n, max(1, int(parts[0]) // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,8 +64,13 @@ def main():
     ap.add_argument("--pairs-per-gpu", type=int, default=0, help="override: fixed shard per rank (weak scaling)")
     ap.add_argument("--kernel", default=os.environ.get("ZKP_KERNEL", "auto"))
     ap.add_argument("--cpu-sample", type=int, default=16384, help="pairs of the oracle leg (parity sample + all-cores baseline)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores oracle leg (default: usable cores, at most 16 per GPU of the job)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bare", action="store_true", help="profiling runs: only warm-up + timed passes reach the GPU (no phase timing, clock "
+                                                        "probe or oracle leg), so that a rocprofv3 counter run holds exactly those passes")
     args = ap.parse_args()
+    if args.bare:
+        args.no_cpu_baseline = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -119,7 +148,7 @@ def main():
     if rank == 0:
         # ---- everything below is measurement bookkeeping outside the timed region
         # dominant-kernel duration: HIP events recorded on the stream the kernels are launched on
-        kern_ms = eng.time_pairing(g1, g2, out_gt, 2)
+        kern_ms = (1e3 * dt / args.steps) if args.bare else eng.time_pairing(g1, g2, out_gt, 2)
 
         def timed_ms(fn, reps=2):
             fn()
@@ -132,20 +161,22 @@ def main():
             return e0.elapsed_time(e1) / reps, r
 
         # the two phases on their own (the *_dev calls fork and join on torch's current stream, so its events see them)
-        ml_ms, ml = timed_ms(lambda: eng.multi_miller_loop(g1, g2, 1))
-        fe_ms, _ = timed_ms(lambda: eng.final_exponentiation(ml))
-        del ml
-        # clock the chip sustains under this load: a one-wavefront probe on a second stream beside a pass
-        side = torch.cuda.Stream(device=dev)
-        eng.pairing_gt_check(g1, g2, 1, out_gt, ok, flag)
-        ticks, wall_khz = eng.clock_probe(side, spin_us=max(20000, int(kern_ms * 500)))
-        torch.cuda.synchronize()
-        tk = ticks.cpu().numpy()
-        sustained_ghz = float(tk[0]) / float(tk[1]) * wall_khz * 1e3 / 1e9 if tk[1] else None
+        ml_ms = fe_ms = sustained_ghz = None
+        if not args.bare:
+            ml_ms, ml = timed_ms(lambda: eng.multi_miller_loop(g1, g2, 1))
+            fe_ms, _ = timed_ms(lambda: eng.final_exponentiation(ml))
+            del ml
+            # clock the chip sustains under this load: a one-wavefront probe on a second stream beside a pass
+            side = torch.cuda.Stream(device=dev)
+            eng.pairing_gt_check(g1, g2, 1, out_gt, ok, flag)
+            ticks, wall_khz = eng.clock_probe(side, spin_us=max(20000, int(kern_ms * 500)))
+            torch.cuda.synchronize()
+            tk = ticks.cpu().numpy()
+            sustained_ghz = float(tk[0]) / float(tk[1]) * wall_khz * 1e3 / 1e9 if tk[1] > 0 else None
 
         value = global_pairs * args.steps / dt
         achieved = (n * MACS_PER_PAIRING) / (kern_ms * 1e-3)
-        phase = lambda fpm, ms: (n * fpm * MACS_PER_FPMUL) / (ms * 1e-3) / PEAK_MACS
+        phase = lambda fpm, ms: ((n * fpm * MACS_PER_FPMUL) / (ms * 1e-3) / PEAK_MACS) if ms else None
         traffic = traffic_src = None
         for rnd in ("r02", "r01"):
             tpath = os.path.join(ROOT, "profiles", rnd, "pmc", "traffic.json")
@@ -162,12 +193,13 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as o  # cpu_baseline leg / checker only
             host_cores = os.cpu_count() or 1
+            threads = args.cpu_threads or min(usable_cores(), 16 * world)
             ns = min(args.cpu_sample, n)
             idx = torch.arange(0, n, n // ns, device=dev)[:ns]
             h1 = g1[idx].cpu().numpy().view(np.uint64)
             h2 = g2[idx].cpu().numpy().view(np.uint64)
             tc = time.perf_counter()
-            want = o.pairing_batch(h1, h2, nthreads=host_cores)
+            want = o.pairing_batch(h1, h2, nthreads=threads)
             t_all = time.perf_counter() - tc
             got = out_gt[idx].cpu().numpy().view(np.uint64)
             parity = bool(np.array_equal(got, want))
@@ -180,7 +212,7 @@ def main():
             slow = o.pairing_batch_slow(h1[:n_slow], h2[:n_slow], nthreads=1)
             t_slow = time.perf_counter() - tc
             parity = parity and bool(np.array_equal(one, want[:n1])) and bool(np.array_equal(slow, want[:n_slow]))
-            cpu = {"value": ns / t_all, "unit": "pairings/s", "cores": host_cores, "kind": "port", "host_cores": host_cores,
+            cpu = {"value": ns / t_all, "unit": "pairings/s", "cores": threads, "kind": "port", "host_cores": host_cores,
                    "single_thread": {"value": n1 / t_one, "unit": "pairings/s", "cores": 1, "sample": "first %d pairs of the sample" % n1},
                    "reference_faithful_slow_mode": {
                        "value": n_slow / t_slow, "unit": "pairings/s", "cores": 1,
@@ -188,7 +220,8 @@ def main():
                                "division per Fp::mul as in the reference's src/fp.rs:416-434, Fermat inversions, no Montgomery form; "
                                "a restatement, NOT the Rust crate (which cannot be built here and has no pairing)",
                        "sample": "first %d pairs of the sample" % n_slow},
-                   "sample": "%d of rank 0's %d pairs (every %d-th), CPU restatement oracle/, %d threads = every host core" % (ns, n, n // ns, host_cores)}
+                   "sample": "%d of rank 0's %d pairs (every %d-th), CPU restatement oracle/, %d threads (the job's CPU share; the host "
+                             "reports %d cores)" % (ns, n, n // ns, threads, host_cores)}
         collective = ("1 RCCL all-reduce(MIN) of the AND flag over %d ranks" % ranks) if ranks > 1 else "one rank: no collective"
         roof = {"bound": "valu-int (neither hbm nor mfma: 384-bit modular arithmetic, >7000 MAC/B)",
                 "achieved": achieved / 1e12, "peak": PEAK_MACS / 1e12, "unit": "T u32-MAC/s",

@@ -2,9 +2,9 @@
 """HBM traffic of one bench.py pass from two rocprofv3 counter runs (FETCH_SIZE and WRITE_SIZE cannot share a
 pass on gfx950: /opt/skills/guides/MI355X_MICROARCH.md, HBM + counter-slot table).
 
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
-    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --pairs 1048576 > profiles/r01/pmc/traffic.json
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --bare
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --bare
+    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --pairs 1048576 > profiles/r02/pmc/traffic.json
 
 Counters are in KB.  gfx950 correction: FETCH_SIZE counts the 128-B requests of 16 B/lane streaming reads at 64 B,
 so it is doubled; WRITE_SIZE is exact for 16 B/lane streaming stores.  The profiled process runs several passes of
@@ -17,7 +17,7 @@ import glob
 import json
 import os
 
-PASS_KERNELS = ("k_prep_lines", "k_coop", "k_batch_inv")
+PASS_KERNELS = ("k_prep_lines", "k_coop", "k_batch_inv", "k_ksq", "k_kdec_a", "k_kdec_b")
 
 
 def short(name):
@@ -51,11 +51,12 @@ def main():
     ap.add_argument("fetch_dir")
     ap.add_argument("write_dir")
     ap.add_argument("--pairs", type=int, required=True, help="pairs per pass of the profiled run")
+    ap.add_argument("--passes", type=int, default=0, help="passes in the profiled run (default: k_ksq dispatches / 5)")
     a = ap.parse_args()
     fetch, dfetch = load(a.fetch_dir, "FETCH_SIZE")
     write, dwrite = load(a.write_dir, "WRITE_SIZE")
-    passes = dfetch["k_batch_inv"]
-    assert passes and passes == dwrite["k_batch_inv"], (dfetch, dwrite)
+    passes = a.passes or dfetch["k_ksq"] // 5      # five x-power chains per pass
+    assert passes and dfetch["k_ksq"] == dwrite["k_ksq"] == 5 * passes, (dfetch, dwrite)
     per = {}
     total = 0.0
     for k in PASS_KERNELS:
@@ -64,15 +65,21 @@ def main():
         per[k] = {"fetch_x2": fx2, "write": w, "dispatches_per_pass": dfetch[k] / passes}
         total += fx2 + w
     # algorithmic bytes of a pass: inputs 288 B + Gt 576 B + ok byte per pair; line stream written and read once
-    # (68 steps x 6 records x 64 B); per-check state records the step programs exchange (counted from the generated
-    # programs: miller 12 stores; fexp_a 12 loads + 9 stores; fexp_c 171 loads + 138 stores; inversion 2 + 2)
+    # (68 steps x 6 records x 64 B); per-check state records the kernels exchange: miller 12 stores; fexp_a 12 loads + 9 stores;
+    # inversion 2; the phase C step programs' K_STATE loads and stores (counted from the generated plan); per x-power chain
+    # k_ksq 8 loads + 6 x 8 stores, k_kdec_a 6 x (8 loads + 5 stores), k_batch_inv 6 x 3, k_kdec_b 6 x (13 loads + 4 stores)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import coopgen
+    prog_state = sum(len(st["lanes"]) for seg in coopgen.fexp_c_segments() for st in seg.steps
+                     if st["op"] in (coopgen.OP_GLOAD, coopgen.OP_GSTORE) and st["kind"] == coopgen.K_STATE)
     n = a.pairs
     lines = 68 * 6 * 64 * 2
-    state = (12 + 12 + 9 + 171 + 138 + 4) * 64
+    state = (12 + 12 + 9 + 2 + prog_state + 5 * (8 + 48 + 6 * 13 + 18 + 6 * 17)) * 64
     algo = n * (288 + 576 + 1 + lines + state)
     out = {
         "workload": "bench.py pass: %d pairs, cooperative family; passes in the profiled run: %d" % (n, passes),
-        "source": "tools/pmc_traffic.py over rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs of `bench.py --steps 1 --warmup 0 --no-cpu-baseline`)",
+        "source": "tools/pmc_traffic.py over rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs of `bench.py --steps 1 --warmup 0 --bare`)",
         "correction": "FETCH_SIZE (KB) doubled (gfx950 tallies 128-B requests of 16 B/lane streaming reads at 64 B); WRITE_SIZE (KB) as is",
         "pairs_per_step": n,
         "hbm_bytes_per_step": total,

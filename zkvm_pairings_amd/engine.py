@@ -408,7 +408,7 @@ class PairingEngine:
         """queue the one-wavefront clock probe on `stream` (a torch.cuda.Stream); -> (tensor of two int64: shader-clock
         ticks, wall-clock ticks; valid once the stream has drained, wall clock rate in kHz)"""
         import torch
-        out = torch.zeros(2, dtype=torch.int64, device=torch.device("cuda", self.device))
+        out = torch.empty(2, dtype=torch.int64, device=torch.device("cuda", self.device))   # no fill: nothing queued on another stream may touch it
         khz = ctypes.c_int(0)
         self._chk(self._lib.zkp_clock_probe_dev(self._h, ctypes.c_void_p(stream.cuda_stream), int(spin_us), self._tp(out), ctypes.byref(khz)))
         return out, khz.value
