@@ -28,6 +28,13 @@ def test_header_symbols_exported_and_bound():
     assert lib.zkp_abi_version() == 2
 
 
+def test_rust_and_c_bindings_list_the_same_symbols():
+    """the (never compiled) Rust -sys crate declares every entry point of the header, nothing else"""
+    with open(os.path.join(ROOT, "integration", "rust", "src", "lib.rs")) as f:
+        rust = sorted(set(re.findall(r"pub fn (zkp_[a-z0-9_]+)\s*\(", f.read())))
+    assert rust == _declared_symbols()
+
+
 def test_gt_identity_and_strerror():
     from zkvm_pairings_amd import PairingEngine, _lib
     one = PairingEngine.gt_identity()

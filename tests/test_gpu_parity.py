@@ -347,7 +347,7 @@ def test_properties_at_size(keng):
 
 @pytest.mark.parametrize("k", [6, 10])
 def test_pairing_check_many_pairs_per_check(keng, k, monkeypatch):
-    """k > 4 pairs per check (processed in groups of four on the cooperative path): cancelling products
+    """many pairs per check (one Miller program up to eight pairs, groups of eight joined by f12mul beyond that): cancelling products
     prod_j e(P_j,Q_j) e(-P_j,Q_j) == 1, every third check broken, infinities in later groups; a chunked
     multi-stream engine must agree with the oracle too."""
     from zkvm_pairings_amd import PairingEngine, synthetic
@@ -382,11 +382,11 @@ def test_pairing_check_many_pairs_per_check(keng, k, monkeypatch):
 
 
 def test_fp12_product_and_one_product_check(keng):
-    """the whole batch as ONE check: Miller product over all pairs (groups of four + product tree), Fp12
+    """the whole batch as ONE check: Miller product over all pairs (eight pairs per accumulator + product tree), Fp12
     product tree on its own, one shared final exponentiation; host and device entry points; odd sizes."""
     import torch
     from zkvm_pairings_amd import synthetic
-    n = 203                                   # 50 groups of four + a group of three; tree sizes 51, 26, 13, 7, 4, 2
+    n = 203                                   # 25 groups of eight + a group of three; tree sizes 26, 13, 7, 4, 2
     g1, g2, _, _ = synthetic.random_pairs(keng, n, seed=909)
     inf1 = np.zeros(n, dtype=np.uint8)
     inf1[[0, 77, 202]] = 1

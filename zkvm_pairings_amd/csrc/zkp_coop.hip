@@ -1329,6 +1329,7 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     ev = getenv("ZKP_COOP_CHUNK");
     d->chunk = ev ? (size_t)atol(ev) : ((size_t)1 << 16);   // measured best: 2 pipes x 2^16 checks
     if (d->chunk < 320) d->chunk = 320;
+    if (d->chunk > ((size_t)1 << 20)) d->chunk = (size_t)1 << 20;   // 8 pairs x 2^20 checks x 2 lanes: every per-launch count stays in 32 bits
     ev = getenv("ZKP_COOP_SUPER");
     d->super = ev ? (size_t)atol(ev) : ((size_t)1 << 20);
     if (d->super < d->chunk) d->super = d->chunk;
