@@ -222,7 +222,8 @@ def main():
                        "sample": "first %d pairs of the sample" % n_slow},
                    "sample": "%d of rank 0's %d pairs (every %d-th), CPU restatement oracle/, %d threads (the job's CPU share; the host "
                              "reports %d cores)" % (ns, n, n // ns, threads, host_cores)}
-        collective = ("1 RCCL all-reduce(MIN) of the AND flag over %d ranks" % ranks) if ranks > 1 else "one rank: no collective"
+        collective = ("1 all-reduce(MIN) of the AND flag over %d ranks (%s)" % (ranks, "RCCL" if backend == "nccl" else backend + ", shared-GPU rehearsal")) \
+            if ranks > 1 else "one rank: no collective"
         roof = {"bound": "valu-int (neither hbm nor mfma: 384-bit modular arithmetic, >7000 MAC/B)",
                 "achieved": achieved / 1e12, "peak": PEAK_MACS / 1e12, "unit": "T u32-MAC/s",
                 "frac": achieved / PEAK_MACS, "traffic": traffic, "traffic_source": traffic_src,

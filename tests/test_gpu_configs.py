@@ -160,7 +160,7 @@ def test_two_ranks_sharded_check_equals_single_rank(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["config"]["pairs_per_gpu"] == 32768
-    assert line["config"]["gt_sample_bit_exact"] is True and "all-reduce(MIN)" in line["config"]["workload"]
+    assert line["config"]["gt_sample_bit_exact"] is True and "all-reduce(MIN)" in line["config"]["workload"] and "gloo" in line["config"]["workload"]
     # and the guard: --gpus must match the number of ranks
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
