@@ -21,6 +21,10 @@ GLOBAL_PAIRS = 1 << 20
 # the Miller loop, 11,116 + 613 for the one inversion in the final exponentiation) x 300 32x32->64 multiply-adds of a
 # 12-limb CIOS multiply
 FPMUL_MILLER, FPMUL_FEXP = 10140, 11116 + 613
+# of the Miller loop's 10,140: the G2 doubling / addition steps with their line coefficients (63 x (3 mul + 8 sqr in Fp2 + 2
+# scalings) + 5 x (7 mul + 8 sqr + 2 scalings), Fp2 mul = 4 and sqr = 2 Fp mul in the reference-shaped count) - the part
+# k_prep_lines computes; the rest is the Fp12 accumulator (line products and squarings): the Miller step program
+FPMUL_LINES = 63 * (3 * 4 + 8 * 2 + 4) + 5 * (7 * 4 + 8 * 2 + 4)
 MACS_PER_FPMUL = 300
 MACS_PER_PAIRING = (FPMUL_MILLER + FPMUL_FEXP) * MACS_PER_FPMUL
 # measured on MI355X (tools/ubench_valu.hip): v_mad_u64_u32 issues one wave-instruction per ~4 cycles per SIMD
@@ -161,7 +165,12 @@ def main():
             return e0.elapsed_time(e1) / reps, r
 
         # the two phases on their own (the *_dev calls fork and join on torch's current stream, so its events see them)
-        ml_ms = fe_ms = sustained_ghz = None
+        ml_ms = fe_ms = sustained_ghz = prep_ms = mil_ms = None
+        if not args.bare and args.kernel in ("auto", "coop"):
+            # the two kernels of the Miller phase on their own, on one 2^16-check chunk (what a launch of the pipeline covers)
+            nk = min(n, 1 << 16)
+            prep_ms = eng.time_coop_step(10, nk) * n / nk
+            mil_ms = eng.time_coop_step(11, nk) * n / nk
         if not args.bare:
             ml_ms, ml = timed_ms(lambda: eng.multi_miller_loop(g1, g2, 1))
             fe_ms, _ = timed_ms(lambda: eng.final_exponentiation(ml))
@@ -235,6 +244,13 @@ def main():
                                     "kernels": "k_prep_lines + k_coop<30,4> (miller1), Gt-less: Miller value to wire"},
                     "final_exponentiation": {"ms": fe_ms, "frac": phase(FPMUL_FEXP, fe_ms), "fp_mul_equivalents": FPMUL_FEXP,
                                              "kernels": "k_coop<24,34> (fexp_a, fexp_c0..5), k_batch_inv, k_ksq, k_kdec_a, k_kdec_b"}},
+                "kernels": {
+                    "k_prep_lines": {"ms": prep_ms, "frac": phase(FPMUL_LINES, prep_ms), "fp_mul_equivalents": FPMUL_LINES,
+                                     "what": "G2 doubling / addition steps + line coefficients; one 2^16-pair launch timed alone, scaled to the shard"},
+                    "k_coop miller": {"ms": mil_ms, "frac": phase(FPMUL_MILLER - FPMUL_LINES, mil_ms), "fp_mul_equivalents": FPMUL_MILLER - FPMUL_LINES,
+                                      "what": "Fp12 accumulator: 68 line products + 63 squarings; one 2^16-check launch timed alone, scaled"},
+                    "final exponentiation kernels": {"ms": fe_ms, "frac": phase(FPMUL_FEXP, fe_ms), "fp_mul_equivalents": FPMUL_FEXP,
+                                                     "what": "fexp_a, k_batch_inv, the phase C plan (see profiles/r02/v20_kernel_stats.txt for its split)"}},
                 "launch": "one pass over the resident batch = phase A per 2^16-check chunk on two overlapped HIP streams (k_prep_lines, k_coop "
                           "miller, k_coop fexp_a), ONE k_batch_inv, then the phase C plan over the whole shard: six step programs "
                           "alternating with five compressed squaring runs (k_ksq) and their decompression (k_kdec_a, k_batch_inv, "

@@ -828,17 +828,26 @@ KSQ_NSQ = X_BITS[-1]                                         # squarings of one 
 KSQ_MASK = sum(1 << (e - 1) for e in X_BITS)                 # snapshot after squaring number e (loop index e - 1)
 
 
-def cyc_exp(b, a, park):
-    """-> (conj(a^|x|) in freshly allocated slots, spill handle of a).  a (cyclotomic subgroup) goes to state area `park`,
-    ONE compressed squaring run (k_ksq) squares it 63 times and keeps the six powers a^(2^e), e the set bits of |x|, the
-    decompression kernels complete them, and the step program multiplies them: a^|x| = prod_e a^(2^e)."""
-    if any(s != 1 for s in a.signs):
-        a = b.copy12(a, a)            # the kernels read raw records: a conjugated view must be materialised
-    assert max(b.kof(s) for s in a.slots) <= Builder.K_INPUT
-    ha = b.spill(a, park)
-    n = len(X_BITS)
-    b.cut([(PLAN_KSQ, park, ST_SNAP, KSQ_NSQ, KSQ_MASK), (PLAN_KDEC_A, ST_SNAP, n, ST_KN), (PLAN_INV, ST_KN, ST_KNINV, n),
-           (PLAN_KDEC_B, ST_SNAP, n, ST_KNINV)])
+def cyc_exp(b, a, park, half=False):
+    """-> (a^x for the curve's NEGATIVE x, i.e. conj(a^|x|), in freshly allocated slots; spill handle of a).  a (cyclotomic
+    subgroup; an LDS-resident V12, or the spill handle of a value that is already parked - then `park` is ignored) goes to
+    the state buffer, ONE compressed squaring run (k_ksq) squares it 63 times and keeps the six powers a^(2^e), e the set
+    bits of |x|, the decompression kernels complete them, and the step program multiplies them: a^|x| = prod_e a^(2^e).
+    half: the exponent is x / 2 (|x| is even: one squaring less, the snapshots one squaring earlier)."""
+    if isinstance(a, V12):
+        if any(s != 1 for s in a.signs):
+            a = b.copy12(a, a)            # the kernels read raw records: a conjugated view must be materialised
+        assert max(b.kof(s) for s in a.slots) <= Builder.K_INPUT
+        ha = b.spill(a, park)
+    else:
+        ha = a
+        park, signs, kb = ha
+        assert all(s == 1 for s in signs) and kb <= Builder.K_INPUT
+    bits = [e - 1 for e in X_BITS] if half else X_BITS
+    assert bits[0] >= 1
+    n = len(bits)
+    b.cut([(PLAN_KSQ, park, ST_SNAP, bits[-1], sum(1 << (e - 1) for e in bits)), (PLAN_KDEC_A, ST_SNAP, n, ST_KN),
+           (PLAN_INV, ST_KN, ST_KNINV, n), (PLAN_KDEC_B, ST_SNAP, n, ST_KNINV)])
     snap = lambda k: (ST_SNAP + 12 * k, [1] * 12, Builder.K_REDUCED)
     r = b.fill(snap(n - 1))
     for k in range(n - 2, -1, -1):
@@ -883,57 +892,43 @@ def prog_fexp_c(to_wire=True):
     # easy part continued: t2 = frob^2(u) * u
     t2 = b.frobenius(b.alloc(12), u, 2)
     t2 = b.fp12_mul(t2, t2, u)
-    # hard part: the upstream-shaped x-chain of DESIGN.md / SURVEY.md S6 (the products of the last lines
-    # are associated differently to bound LDS residency; exact field arithmetic => same value)
+    # hard part: r^((x-1)^2 (x+p) (x^2+p^2-1) + 3) = r^(3 (p^4-p^2+1)/r) (Hayashida-Hayasaka-Teruya, ePrint 2020/875) - the same
+    # power as the upstream-shaped chain of SURVEY.md S6 (the oracle's; tests/test_coopgen.py holds both against the model), with
+    # five x-power chains, 7 products and one Granger-Scott squaring outside them instead of 10 and 2.  x is negative: a^x
+    # is conj(a^|x|), and inverses in the cyclotomic subgroup are conjugates (free sign views).
     SP = [ST_SPILL + 12 * i for i in range(8)]
-    t1 = b.cyclotomic_sqr(u, t2).conj()              # resident: t2 t1
-    h1 = b.spill(t1, SP[0])
-    t3, h2 = cyc_exp(b, t2, SP[1])                   # t3
-    t4 = b.cyclotomic_sqr(b.alloc(12), t3)           # t3 t4
-    h4 = b.spill(t4, SP[2])
-    t1 = b.fill(h1)                                  # t3 t1
-    t5 = b.fp12_mul(t1, t1, t3)                      # t3 t5
-    h3 = b.spill(t3, SP[0])
-    t1, h5 = cyc_exp(b, t5, SP[3])                   # t1
-    t0, h1 = cyc_exp(b, t1, SP[4])                   # t0
-    t6, h0 = cyc_exp(b, t0, SP[5])                   # t6
-    t4 = b.fill(h4)                                  # t6 t4
-    t6 = b.fp12_mul(t6, t6, t4)
-    b.release(t4.slots)
-    t4, h6 = cyc_exp(b, t6, SP[7])                   # t4
-    h4 = b.spill(t4, SP[2])
-    t6 = b.fill(h6)
-    t2 = b.fill(h2)                                  # t6 t2
-    t6 = b.fp12_mul(t6, t6, t2.conj())
-    t6 = b.frobenius(t6, t6, 1)
-    h6 = b.spill(t6, SP[6])
-    t5 = b.fill(h5)                                  # t2 t5
-    t5 = b.fp12_mul(t5, t5.conj(), t2)
-    b.release(t2.slots)
-    t4 = b.fill(h4)                                  # t5 t4
-    t4 = b.fp12_mul(t4, t4, t5)
-    b.release(t5.slots)
-    h4 = b.spill(t4, SP[2])
-    t1 = b.fill(h1)
-    t2 = b.fill(h2)                                  # t1 t2
-    t1 = b.fp12_mul(t1, t1, t2)
-    b.release(t2.slots)
-    t1 = b.frobenius(t1, t1, 3)
-    t4 = b.fill(h4)                                  # t1 t4
-    t1 = b.fp12_mul(t1, t1, t4)
-    b.release(t4.slots)
-    t6 = b.fill(h6)                                  # t1 t6
-    t1 = b.fp12_mul(t1, t1, t6)
-    b.release(t6.slots)
-    h1 = b.spill(t1, SP[4])
-    t3 = b.fill(h3)
-    t0 = b.fill(h0)                                  # t3 t0
-    t3 = b.fp12_mul(t3, t3, t0)
-    b.release(t0.slots)
-    t3 = b.frobenius(t3, t3, 2)
-    t1 = b.fill(h1)                                  # t3 t1
-    t3 = b.fp12_mul(t3, t3, t1)
-    b.release(t1.slots)
+    r = t2                                           # resident: r (and u's slots, free for reuse)
+    sq = b.cyclotomic_sqr(u, r)                      # r^2                         resident: r, r^2
+    hr = b.spill(r, SP[0])
+    a1, hsq = cyc_exp(b, sq, SP[1], half=True)       # (r^2)^(x/2) = r^x
+    rr = b.fill(hr)
+    a1 = b.fp12_mul(a1, a1, rr.conj())               # r^(x-1)
+    b.release(rr.slots)
+    a2, h1 = cyc_exp(b, a1, SP[2])                   # r^((x-1) x)                 parked: r^(x-1)
+    a1 = b.fill(h1)
+    a1 = b.fp12_mul(a1, a1.conj(), a2)               # r^((x-1)^2)
+    b.release(a2.slots)
+    a2, h1 = cyc_exp(b, a1, SP[3])                   # r^((x-1)^2 x)               parked: r^((x-1)^2)
+    a1 = b.fill(h1)
+    a1 = b.frobenius(a1, a1, 1)                      # r^((x-1)^2 p)
+    a1 = b.fp12_mul(a1, a1, a2)                      # c = r^((x-1)^2 (x+p))
+    b.release(a2.slots)
+    hc = b.spill(a1, SP[4])
+    rr = b.fill(hr)
+    s2 = b.fill(hsq)
+    rr = b.fp12_mul(rr, rr, s2)                      # r^3
+    b.release(s2.slots)
+    h3 = b.spill(rr, SP[0])
+    a0, _ = cyc_exp(b, hc, None)                     # c^x
+    a2, _ = cyc_exp(b, a0, SP[5])                    # c^(x^2)
+    a1 = b.fill(hc)
+    a2 = b.fp12_mul(a2, a2, a1.conj())               # c^(x^2 - 1)
+    a1 = b.frobenius(a1, a1, 2)                      # c^(p^2)
+    a2 = b.fp12_mul(a2, a2, a1)                      # c^(x^2 + p^2 - 1)
+    b.release(a1.slots)
+    rr = b.fill(h3)
+    t3 = b.fp12_mul(rr, rr, a2)
+    b.release(a2.slots)
     finish_output(b, t3, to_wire, ST_F, check_identity=True)
     return b.finish_plan()
 

@@ -1675,22 +1675,30 @@ hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, ui
     return hipSuccess;
 }
 
-// timing hook (diagnostic): one of the synthetic programs (tools/coopgen.py prog_timing; which 0..8) or 400 squarings of the
-// compressed squaring-run kernel (which 9) over n checks, on the caller's stream, timed with the events handed in
+// timing hook (diagnostic): one of the synthetic programs (tools/coopgen.py prog_timing; which 0..8), 400 squarings of the
+// compressed squaring-run kernel (which 9), the line precomputation of n pairs (which 10) or the one-pair Miller program
+// over the line stream it left behind (which 11; call 10 first) - on the caller's stream, timed with the events handed in.
+// The kernels' running time does not depend on the data (zeroed buffers serve as inputs).
 hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, hipEvent_t e0, hipEvent_t e1, float* ms) {
     CoopDev* d = (CoopDev*)st->d_prog;
     static const int ids[9] = {ZKP_PROG_TIME_T1, ZKP_PROG_TIME_T3, ZKP_PROG_TIME_T3E, ZKP_PROG_TIME_T6, ZKP_PROG_TIME_T12, ZKP_PROG_TIME_LIN,
                                ZKP_PROG_TIME_CYC, ZKP_PROG_TIME_CYCSD, ZKP_PROG_TIME_FILL};
-    if (which < 0 || which > 9 || !n || n > 0x7fffffffu) return hipErrorInvalidValue;
+    if (which < 0 || which > 11 || !n || n > 0x7fffffffu || (which >= 10 && n > d->chunk)) return hipErrorInvalidValue;
     hipError_t e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, (size_t)ST_SIZE * n * 64);
     if (e != hipSuccess) return e;
+    if (which >= 10 && (e = ensure_buf(&d->pipe[0].lines, &d->pipe[0].lines_bytes, (size_t)NLINES * 6 * n * 64)) != hipSuccess) return e;
     CoopPipe v = d->pipe[0];
     v.stream = s;
     auto once = [&]() -> hipError_t {
         if (which == 9) return run_ksq(s, v.state, (uint32_t)n, (uint32_t)n, 0, 12, 400, 1ull << 63);
+        if (which == 10) {
+            const uint64_t* zero = (const uint64_t*)v.state;      // 36 u64 of zeros per pair: the state buffer is far larger
+            return prep(&v, zero, zero + 12 * n, nullptr, nullptr, 0, (uint32_t)n, 1, 0, 1);
+        }
+        if (which == 11) return run_prog(d, &v, ZKP_PROG_MILLER1_STATE, (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
         return run_prog(d, &v, ids[which], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
     };
-    if ((e = hipMemsetAsync(v.state, 0, (size_t)ST_SIZE * n * 64, s)) != hipSuccess) return e;
+    if (which != 11 && (e = hipMemsetAsync(v.state, 0, (size_t)ST_SIZE * n * 64, s)) != hipSuccess) return e;
     if ((e = once()) != hipSuccess) return e;
     if ((e = hipEventRecord(e0, s)) != hipSuccess) return e;
     if ((e = once()) != hipSuccess) return e;

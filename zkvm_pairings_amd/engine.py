@@ -413,6 +413,12 @@ class PairingEngine:
         self._chk(self._lib.zkp_clock_probe_dev(self._h, ctypes.c_void_p(stream.cuda_stream), int(spin_us), self._tp(out), ctypes.byref(khz)))
         return out, khz.value
 
+    def time_coop_step(self, which, n):
+        """ms of one launch of a diagnostic / single-kernel timing run (zkp_time_coop_step)"""
+        ms = ctypes.c_float()
+        self._chk(self._lib.zkp_time_coop_step(self._h, int(which), int(n), ctypes.byref(ms)))
+        return ms.value
+
     def time_pairing(self, g1, g2, out, reps):
         """avg ms per launch of the fused pairing kernel, HIP events on the engine's own stream."""
         n = self._t_pairs(g1, g2, None, None)
