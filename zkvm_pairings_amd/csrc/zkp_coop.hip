@@ -1143,10 +1143,14 @@ __global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks
     int4* I = state + (size_t)elem_ninv * nc * 4;
     Fp28 acc = f_const(K28_ONE);
     uint32_t cnt = 0;
+    // both loops ask for the next element's records before they work on the current one: a lane's chain is strictly
+    // sequential and only a few wavefronts share a SIMD here, so an exposed load latency per step is not covered by anyone
+    Fp28 e_next;
+    rec_load(e_next, N + recno(i));
 #pragma unroll 1
     for (uint32_t idx = i; idx < total && cnt < B; idx += L, cnt++) {
-        Fp28 e;
-        rec_load(e, N + recno(idx));
+        Fp28 e = e_next;
+        if (idx + L < total && cnt + 1 < B) rec_load(e_next, N + recno(idx + L));
         if (B > 1) {
             rec_store(I + recno(idx), acc);
             if (f_is_zero(e)) e = f_const(K28_ONE);
@@ -1157,12 +1161,21 @@ __global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks
     }
     Fp28 inv = fermat ? f_inv_fermat(acc) : f_inv(acc);
     if (B == 1) { rec_store(I + recno(i), inv); return; }
+    Fp28 pre_next;
+    if (cnt) {
+        const size_t at = recno(i + (cnt - 1) * L);
+        rec_load(e_next, N + at);
+        rec_load(pre_next, I + at);
+    }
 #pragma unroll 1
     for (uint32_t j = cnt; j-- > 0;) {
         const size_t at = recno(i + j * L);
-        Fp28 e, pre, r;
-        rec_load(e, N + at);
-        rec_load(pre, I + at);
+        Fp28 e = e_next, pre = pre_next, r;
+        if (j) {
+            const size_t nx = recno(i + (j - 1) * L);
+            rec_load(e_next, N + nx);
+            rec_load(pre_next, I + nx);
+        }
         if (f_is_zero(e)) {
             f_zero(r);
         } else {
@@ -1202,7 +1215,8 @@ __global__ void __launch_bounds__(64, 2) k_kdec_a(int4* state, uint32_t n_checks
     Fp28 na = c ? c_add(o, s5) : c_sub(s5, o);                 // xi z5^2
     Fp28 s4 = f.sqr(z4);
     na = c_sub(c_add(na, c_add(c_dbl(s4), s4)), c_dbl(z3));
-    Fp28 nb = c_dbl(f.mul(z4, z5));
+    Fp28 nb = na;
+    if (__any(z2_zero)) nb = c_dbl(f.mul(z4, z5));             // wave-uniform: almost never taken (z2 = 0: the identity)
     Fp28 N = z2_zero ? nb : na, D = z2_zero ? z3 : z2;
     swap_pair(o, D);
     Acc acc;
