@@ -164,3 +164,28 @@ def test_two_ranks_sharded_check_equals_single_rank(tmp_path):
     # and the guard: --gpus must match the number of ranks
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
+
+
+def test_rccl_all_reduce_min_on_one_rank():
+    """the path's only collective through RCCL itself (backend "nccl" on ROCm), as far as one GPU allows: a single-rank
+    process group, all_reduce(MIN) of the int32 AND flag and the all_gather of a 576-byte Fp12 value on the device"""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from zkvm_pairings_amd import dist as zd
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29519")
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+for v in (0, 1):
+    f = torch.tensor([v], dtype=torch.int32, device=dev)
+    dist.all_reduce(f, op=dist.ReduceOp.MIN)
+    assert int(f.item()) == v
+part = torch.arange(72, dtype=torch.int64, device=dev)
+out = [torch.empty_like(part)]
+dist.all_gather(out, part)
+assert torch.equal(out[0], part)
+assert zd.max_over_ranks(1.5, dev) == 1.5
+dist.barrier(); dist.destroy_process_group(); print("RCCL ONE RANK OK")
+'''
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "RCCL ONE RANK OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
