@@ -250,7 +250,7 @@ def main():
                     "k_coop miller": {"ms": mil_ms, "frac": phase(FPMUL_MILLER - FPMUL_LINES, mil_ms), "fp_mul_equivalents": FPMUL_MILLER - FPMUL_LINES,
                                       "what": "Fp12 accumulator: 68 line products + 63 squarings; one 2^16-check launch timed alone, scaled"},
                     "final exponentiation kernels": {"ms": fe_ms, "frac": phase(FPMUL_FEXP, fe_ms), "fp_mul_equivalents": FPMUL_FEXP,
-                                                     "what": "fexp_a, k_batch_inv, the phase C plan (see profiles/r02/v20_kernel_stats.txt for its split)"}},
+                                                     "what": "fexp_a, k_batch_inv, the phase C plan (see profiles/r02/v21_kernel_stats.txt for its split)"}},
                 "launch": "one pass over the resident batch = phase A per 2^16-check chunk on two overlapped HIP streams (k_prep_lines, k_coop "
                           "miller, k_coop fexp_a), ONE k_batch_inv, then the phase C plan over the whole shard: six step programs "
                           "alternating with five compressed squaring runs (k_ksq) and their decompression (k_kdec_a, k_batch_inv, "
