@@ -88,8 +88,10 @@ typedef enum {
     ZKP_TOWER_FP12_FROBENIUS = 8,           /* x^p */
     ZKP_TOWER_FP12_CONJUGATE = 9,
     ZKP_TOWER_FP12_CYCLOTOMIC_SQUARE = 10,  /* Granger-Scott; input in the cyclotomic subgroup */
-    ZKP_TOWER_FP12_CYCLOTOMIC_POW2K = 11    /* g^(2^repeat), 1 <= repeat <= 64: compressed squarings + decompression
+    ZKP_TOWER_FP12_CYCLOTOMIC_POW2K = 11,   /* g^(2^repeat), 1 <= repeat <= 64: compressed squarings + decompression
                                                (the building block of the final exponentiation's x-power chains) */
+    ZKP_TOWER_FP12_CYCLOTOMIC_DECOMPRESS = 12 /* Karabina decompression: c0.c0 and c1.c1 of the result are recomputed from
+                                               the other four Fp2 coefficients of the record (cooperative family only) */
 } zkp_tower_op;
 
 /* which Miller-loop/final-exp kernel family the context uses */

@@ -129,6 +129,21 @@ def test_compressed_squaring_run_and_decompression():
     cg.emu_inv(state, cg.ST_KN, cg.ST_KNINV, 1)
     cg.emu_kdec_b(state, cg.ST_SNAP, 1, cg.ST_KNINV)
     assert [cg.from_mont(state[cg.ST_SNAP + i]) for i in range(12)] == [1] + [0] * 11
+    # the exceptional branch z2 == 0, z3 != 0 (z1 = 2 z4 z5 / z3) on an artificial record: the formulas, not a group element
+    g = m.SplitMix64(5)
+    z3, z4, z5 = [(g.below(m.P), g.below(m.P)) for _ in range(3)]
+    flat = [0] * 12
+    for pos, z in ((2, z3), (1, z4), (5, z5)):
+        flat[2 * pos], flat[2 * pos + 1] = z
+    state = {cg.ST_SNAP + i: cg.mont(v) for i, v in enumerate(flat)}
+    cg.emu_kdec_a(state, cg.ST_SNAP, 1, cg.ST_KN)
+    cg.emu_inv(state, cg.ST_KN, cg.ST_KNINV, 1)
+    cg.emu_kdec_b(state, cg.ST_SNAP, 1, cg.ST_KNINV)
+    sc = lambda a, k: ((a[0] * k) % m.P, (a[1] * k) % m.P)
+    z1 = m.f2_mul(sc(m.f2_mul(z4, z5), 2), m.f2_inv(z3))
+    z0 = m.f2_add(m.f2_mul_xi(m.f2_sub(sc(m.f2_sqr(z1), 2), sc(m.f2_mul(z3, z4), 3))), (1, 0))
+    got = [cg.from_mont(state[cg.ST_SNAP + i]) for i in range(12)]
+    assert (got[0], got[1]) == z0 and (got[8], got[9]) == z1
     # the plan's mask is the set bits of |x|
     assert cg.X_BITS == [16, 48, 57, 60, 62, 63] and cg.KSQ_NSQ == 63
 

@@ -139,6 +139,57 @@ def test_tower_ops_direct_vs_oracle(keng, ref_kats):
     assert keng.tower_op("fp12_mul", a12[:0], b12[:0]).shape == (0, 72)
 
 
+def _decompress_model(z2, z3, z4, z5):
+    """Karabina decompression in this tower's coordinates with Python integers (the formulas k_kdec_a / k_kdec_b implement;
+    0 / 0 := 0) -> (z0, z1)"""
+    sc = lambda a, k: ((a[0] * k) % m.P, (a[1] * k) % m.P)
+    if z2 != (0, 0):
+        num = m.f2_sub(m.f2_add(m.f2_mul_xi(m.f2_sqr(z5)), sc(m.f2_sqr(z4), 3)), sc(z3, 2))
+        den = sc(z2, 4)
+    else:
+        num, den = sc(m.f2_mul(z4, z5), 2), z3
+    z1 = m.f2_mul(num, m.f2_inv(den)) if den != (0, 0) else (0, 0)
+    z0 = m.f2_add(m.f2_mul_xi(m.f2_sub(m.f2_add(sc(m.f2_sqr(z1), 2), m.f2_mul(z2, z5)), sc(m.f2_mul(z3, z4), 3))), (1, 0))
+    return z0, z1
+
+
+def test_decompression_kernels_incl_exceptional_branches(eng):
+    """k_kdec_a / k_batch_inv / k_kdec_b on their own (ZKP_TOWER_FP12_CYCLOTOMIC_DECOMPRESS): real cyclotomic elements
+    decompress to themselves; records with z2 = 0 (the 2 z4 z5 / z3 branch), z2 = z3 = 0 (0 / 0 := 0) and all four zero
+    (the identity) follow the formulas, checked against Python integers."""
+    from zkvm_pairings_amd import synthetic
+    n = 48
+    g1, g2, _, _ = synthetic.random_pairs(eng, 16, seed=777)
+    gt = o.pairing_batch(g1, g2, nthreads=NTHREADS)                  # members of the cyclotomic subgroup
+    g = m.SplitMix64(99)
+    rec = np.zeros((n, 72), dtype=np.uint64)
+    rec[:16] = gt
+    rec[:16, 0:12] = rnd_fp_arr(5, 32).reshape(16, 12)               # whatever sits in z0 (c0.c0) and z1 (c1.c1) must not matter
+    rec[:16, 48:60] = rnd_fp_arr(6, 32).reshape(16, 12)
+    pos = {2: 36, 3: 24, 4: 12, 5: 60}                               # u64 offset of z2 (c1.c0), z3 (c0.c2), z4 (c0.c1), z5 (c1.c2)
+    zs = []
+    for i in range(16, n):
+        z = {k: (g.below(m.P), g.below(m.P)) for k in (2, 3, 4, 5)}
+        if i % 4 != 0:
+            z[2] = (0, 0)                                            # exceptional: z2 == 0
+        if i % 4 == 2:
+            z[3] = (0, 0)                                            # ... and z3 == 0 as well
+        if i % 4 == 3:
+            z[4] = z[5] = z[3] = (0, 0)                              # the identity's compressed form
+        zs.append(z)
+        for k, off in pos.items():
+            rec[i, off:off + 6], rec[i, off + 6:off + 12] = o.to_limbs(z[k][0]), o.to_limbs(z[k][1])
+    got = eng.tower_op("fp12_cyclotomic_decompress", rec)
+    assert np.array_equal(got[:16], gt)
+    for i, z in zip(range(16, n), zs):
+        z0, z1 = _decompress_model(z[2], z[3], z[4], z[5])
+        want = rec[i].copy()
+        want[0:6], want[6:12] = o.to_limbs(z0[0]), o.to_limbs(z0[1])
+        want[48:54], want[54:60] = o.to_limbs(z1[0]), o.to_limbs(z1[1])
+        assert np.array_equal(got[i], want), i
+    assert np.array_equal(got[n - 1], eng.gt_identity())
+
+
 def test_scalar_mul_golden_and_oracle(keng, model_vectors):
     eng = keng
     from zkvm_pairings_amd import synthetic

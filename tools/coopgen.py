@@ -1536,11 +1536,12 @@ def prog_tower(op):
     return out_wire(r)
 
 
-def prog_tower_to_state():
-    """wire record -> Montgomery limbs in state elements 0..11 (input of a compressed squaring run)"""
+def prog_tower_to_state(base=0):
+    """wire record -> Montgomery limbs in state elements base..base+11 (0: input of a compressed squaring run; ST_SNAP:
+    a snapshot whose z0, z1 the decompression kernels are to recover)"""
     b = Builder()
     f = load_input(b, True)
-    b.gstore(K_STATE, [(f.slots[i], i) for i in range(12)])
+    b.gstore(K_STATE, [(f.slots[i], base + i) for i in range(12)])
     return b
 
 
@@ -1653,6 +1654,7 @@ PROGRAMS = {
 for _op in TOWER_OPS:
     PROGRAMS["tw_" + _op] = (lambda op=_op: prog_tower(op))
 PROGRAMS["tw_to_state"] = prog_tower_to_state
+PROGRAMS["tw_to_snap"] = lambda: prog_tower_to_state(ST_SNAP)
 PROGRAMS["tw_from_snap"] = prog_tower_from_snap
 for _i in range(len(fexp_c_segments())):
     PROGRAMS["fexp_c%d" % _i] = (lambda i=_i: fexp_c_segments()[i])

@@ -1657,14 +1657,14 @@ hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, c
 }
 
 // zkp_tower_op_batch on the cooperative family: `ab` holds the n a-records followed by the n b-records (wire format);
-// op as in zkp_tower_op (include/zkp_pairings.h).  The cyclotomic power g^(2^repeat) takes the route of the final
+// op as in zkp_tower_op (include/zkp_pairings.h).  The cyclotomic power g^(2^repeat) (and the decompression alone) takes the route of the final
 // exponentiation's x-power chains: wire -> state, one compressed squaring run with a single snapshot, decompression, -> wire.
 hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, uint32_t repeat, uint64_t* out, hipStream_t s) {
     CoopDev* d = (CoopDev*)st->d_prog;
     static const int progs[11] = {ZKP_PROG_TW_FP2_MUL, ZKP_PROG_TW_FP2_SQR, ZKP_PROG_TW_FP6_MUL, ZKP_PROG_TW_FP6_SQR, ZKP_PROG_TW_FP12_FROB,
                                   ZKP_PROG_TW_FP12_MUL, ZKP_PROG_TW_FP12_SQR, ZKP_PROG_TW_FP12_014, ZKP_PROG_TW_FP12_FROB, ZKP_PROG_TW_FP12_CONJ,
                                   ZKP_PROG_TW_CYC_SQR};
-    if (op < 0 || op > 11 || n > 0x3fffffffu) return hipErrorInvalidValue;
+    if (op < 0 || op > 12 || n > 0x3fffffffu) return hipErrorInvalidValue;
     hipError_t e;
     for (size_t base = 0; base < n; base += d->chunk) {
         const uint32_t m = (uint32_t)(n - base < d->chunk ? n - base : d->chunk);
@@ -1674,11 +1674,15 @@ hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, ui
             if ((e = run_prog(d, &v, progs[op], m, m, 1, ab + 72 * base, out + 72 * base, nullptr, nullptr, 0, (uint32_t)n)) != hipSuccess) return e;
             continue;
         }
-        if (repeat < 1 || repeat > 64) return hipErrorInvalidValue;
+        if (op == 11 && (repeat < 1 || repeat > 64)) return hipErrorInvalidValue;
         if ((e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, (size_t)ST_SIZE * d->chunk * 64)) != hipSuccess) return e;
         v.state = d->pipe[0].state;
-        if ((e = run_prog(d, &v, ZKP_PROG_TW_TO_STATE, m, m, 1, ab + 72 * base, nullptr, nullptr, nullptr)) != hipSuccess) return e;
-        if ((e = run_ksq(s, v.state, m, m, 0, ZKP_COOP_ST_SNAP, repeat, 1ull << (repeat - 1))) != hipSuccess) return e;
+        if (op == 12) {      // decompression alone: the record's z2..z5 are the snapshot
+            if ((e = run_prog(d, &v, ZKP_PROG_TW_TO_SNAP, m, m, 1, ab + 72 * base, nullptr, nullptr, nullptr)) != hipSuccess) return e;
+        } else {
+            if ((e = run_prog(d, &v, ZKP_PROG_TW_TO_STATE, m, m, 1, ab + 72 * base, nullptr, nullptr, nullptr)) != hipSuccess) return e;
+            if ((e = run_ksq(s, v.state, m, m, 0, ZKP_COOP_ST_SNAP, repeat, 1ull << (repeat - 1))) != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(k_kdec_a, dim3((2 * m + 63) / 64), dim3(64), 0, s, v.state, m, m, (uint32_t)ZKP_COOP_ST_SNAP, 1u, (uint32_t)ZKP_COOP_ST_KN);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = run_inv(d, s, v.state, m, m, ZKP_COOP_ST_KN, ZKP_COOP_ST_KNINV, 1)) != hipSuccess) return e;

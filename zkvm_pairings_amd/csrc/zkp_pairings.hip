@@ -1153,7 +1153,8 @@ int zkp_fp_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, si
 
 int zkp_tower_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint32_t repeat, uint64_t* out) {
     const bool binary = op == ZKP_TOWER_FP2_MUL || op == ZKP_TOWER_FP6_MUL || op == ZKP_TOWER_FP12_MUL || op == ZKP_TOWER_FP12_MUL_BY_014;
-    if (!c || op < 0 || op > ZKP_TOWER_FP12_CYCLOTOMIC_POW2K || n > 0x3fffffffu || (n && (!a || !out || (binary && !b)))) return ZKP_ERR_ARG;
+    if (!c || op < 0 || op > ZKP_TOWER_FP12_CYCLOTOMIC_DECOMPRESS || n > 0x3fffffffu || (n && (!a || !out || (binary && !b)))) return ZKP_ERR_ARG;
+    if (op == ZKP_TOWER_FP12_CYCLOTOMIC_DECOMPRESS && !zkp::coop_selected(&c->coop, c->kernel)) return ZKP_ERR_ARG;
     if (op == ZKP_TOWER_FP12_CYCLOTOMIC_POW2K && (repeat < 1 || repeat > 64)) return ZKP_ERR_ARG;
     if (!n) return ZKP_OK;
     int rc = bind(c);

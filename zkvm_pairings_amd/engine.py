@@ -265,7 +265,7 @@ class PairingEngine:
 
     FP_OPS = {"mul": 0, "add": 1, "sub": 2, "neg": 3, "square": 4, "invert": 5}
     TOWER_OPS = {"fp2_mul": 0, "fp2_square": 1, "fp6_mul": 2, "fp6_square": 3, "fp6_frobenius": 4, "fp12_mul": 5, "fp12_square": 6,
-                 "fp12_mul_by_014": 7, "fp12_frobenius": 8, "fp12_conjugate": 9, "fp12_cyclotomic_square": 10, "fp12_cyclotomic_pow2k": 11}
+                 "fp12_mul_by_014": 7, "fp12_frobenius": 8, "fp12_conjugate": 9, "fp12_cyclotomic_square": 10, "fp12_cyclotomic_pow2k": 11, "fp12_cyclotomic_decompress": 12}
 
     def fp_op(self, op, a, b=None, core28=False):
         """zkVM-precompile-shaped batched field op: op 0 = mul, 1 = add (reference src/fp.rs:376,443), 2 sub, 3 neg,
