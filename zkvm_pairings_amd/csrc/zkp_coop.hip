@@ -13,10 +13,16 @@
 //                  the optional epilogue (alpha r + beta E, renormalised) and the companion store
 //                  (x0 + x1 / x0 - x1 of the lane pair's Fp2 coefficient, so that later steps fetch their
 //                  operand forms ready-made) ride on the MULACC step.
-//   k_batch_inv    the single Fp inversion of the final exponentiation, up to 32 checks per lane (Montgomery's trick).
-// Programs: miller{k}_{state|wire}, f12mul_{state|wire|pairs}, fexp_a_{state|wire}, fexp_c (zkp_coop_prog.inc).
+//   k_batch_inv    batched Fp inversions (Montgomery's trick, up to 32 values per lane, division steps): the single inversion
+//                  of the final exponentiation and the six per x-power chain of the decompression.
+//   k_ksq          the 63 cyclotomic squarings of an x-power chain in Karabina's compressed form: four lanes per check (one Fp2
+//                  product each), 16 checks per wavefront, operands in registers, products exchanged by DPP, snapshots of the
+//                  running value at the set bits of |x|.
+//   k_kdec_a / _b  decompression of the snapshots (two lanes per snapshot) around one k_batch_inv call.
+// Programs: miller{k}_{state|wire}, f12mul_{state|wire|pairs}, fexp_a_{state|wire}, fexp_c0..5, tw_* (zkp_coop_prog.inc).
 // Host side: a super-chunk of up to 2^20 checks shares one state buffer; phase A (lines, Miller loop, fexp_a) runs per
-// 2^16-check chunk on two HIP streams, then ONE k_batch_inv and ONE fexp_c launch cover the super-chunk (two_phase).
+// 2^16-check chunk on two HIP streams, then ONE k_batch_inv and the phase C plan (ZKP_FEXP_C_PLAN: six step programs
+// alternating with the five x-power chains = k_ksq, k_kdec_a, k_batch_inv, k_kdec_b) cover the super-chunk (two_phase).
 //
 // Reference anchors: Fp12::mul_by_014 src/fp12.rs:99-111, Fp12::square :173-184, Fp12::invert
 // :186-190 (+ src/fp6.rs:291-309, src/fp2.rs:278-296), conjugate :123-125; pairing semantics
