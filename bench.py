@@ -116,7 +116,7 @@ def main():
         lo, hi = zdist.shard_range(args.pairs, rank, world)
         global_pairs, scaling = args.pairs, "strong"
     n = hi - lo
-    g1, g2, _, _ = synthetic.random_pairs(eng, n, seed=synthetic.SEED, offset=lo, device_tensors=True)
+    g1, g2, sc_a, sc_b = synthetic.random_pairs(eng, n, seed=synthetic.SEED, offset=lo, device_tensors=True)
     out_gt = torch.empty((n, 72), dtype=torch.int64, device=dev)
     ok = torch.empty(n, dtype=torch.uint8, device=dev)
     flag = torch.empty(1, dtype=torch.int32, device=dev)
@@ -212,6 +212,11 @@ def main():
             t_all = time.perf_counter() - tc
             got = out_gt[idx].cpu().numpy().view(np.uint64)
             parity = bool(np.array_equal(got, want))
+            # the inputs themselves come from the GPU scalar multiplication: pin a sample of them to the oracle's [a] G1gen, [b] G2gen
+            hi_ = idx[:64].cpu().numpy()
+            inputs_ok = bool(np.array_equal(h1[:64], o.g1_mul_batch(np.tile(synthetic.G1_GENERATOR, (len(hi_), 1)), sc_a[hi_])) and
+                             np.array_equal(h2[:64], o.g2_mul_batch(np.tile(synthetic.G2_GENERATOR, (len(hi_), 1)), sc_b[hi_])))
+            parity = parity and inputs_ok
             n1 = min(512, ns)
             tc = time.perf_counter()
             one = o.pairing_batch(h1[:n1], h2[:n1], nthreads=1)
