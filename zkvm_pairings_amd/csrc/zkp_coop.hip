@@ -121,8 +121,14 @@ __device__ __forceinline__ void canon28(uint32_t* f, const int32_t* x) {
     for (int i = 0; i < NL; i++) f[i] = (uint32_t)(neg ? z[i] : (ge ? y[i] : u[i]));
 }
 
+#ifndef ZKP_COOP_KARATSUBA
+#define ZKP_COOP_KARATSUBA 1   // acc_mul_k: 147 multiply-adds per product block instead of 196 (zkp_fp28.hpp); measured on one box,
+                               // 2^20-pair pass: 296.5 ms -> 283.3 ms
+#endif
 #ifndef ZKP_COOP_WAVES
-#define ZKP_COOP_WAVES 4   // 128 VGPRs; with 24-slot programs 16 waves fit a CU (LDS 8-10 KB per wave)
+#define ZKP_COOP_WAVES 2   // register bound only: the Karatsuba accumulators (80 VGPRs) + prefetched operands need 168 VGPRs = 3 waves
+                           // per SIMD (12 x 10 KB of LDS per CU).  Measured alternatives: bound 3 -> 4 spilled VGPRs, 290.7 ms;
+                           // bound 4 (128 VGPRs, 86 spilled) -> 925 ms; without Karatsuba 4 waves x 128 VGPRs: 296.5 ms
 #endif
 // S slots per group and SC constants: two instantiations with the same LDS footprint (10,096 B per wavefront) -
 // <24, 34> for programs that need the whole constants table, <30, 4> for the Miller programs (30 slots, 4 constants)
@@ -164,11 +170,15 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             const uint32_t T = arg;
             Acc acc;
             acc_zero(acc);
+#if ZKP_COOP_KARATSUBA
+            AccMid mid;
+            mid_zero(mid);
+#endif
             uint32_t w = tbl[off + lig];
             uint32_t wn = T > 1 ? tbl[off + LIG + lig] : 0;
             const uint32_t ew = tbl[off + T * LIG + lig];
             // primary operands are prefetched one term ahead; the (rarer) second operands are fetched at
-            // the top of their term - this keeps the kernel at 128 VGPRs = 4 waves per SIMD
+            // the top of their term (14 fewer live registers)
             int32_t xa[NL], xb[NL];
             ld(xa, w & 127);
             ld(xb, (w >> 14) & 127);
@@ -216,8 +226,15 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                     ld(xa, w & 127);
                     ld(xb, (w >> 14) & 127);
                 }
+#if ZKP_COOP_KARATSUBA
+                acc_mul_k(acc, mid, a, b);
+#else
                 acc_mul(acc, a, b);
+#endif
             }
+#if ZKP_COOP_KARATSUBA
+            acc_fold(acc, mid);
+#endif
             int32_t r[NL];
             acc_reduce(r, acc);
             if (h1 & 1) {  // step-uniform: epilogue dst = alpha r + beta E, renormalised
