@@ -174,16 +174,18 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             AccMid mid;
             mid_zero(mid);
 #endif
+            // software pipeline: the table word of term t + 2 is requested at the top of term t and taken over at its
+            // end, behind the multiply-adds (the table is padded: the read past the last term is harmless); the LDS
+            // operands of term t + 1 are requested before the multiply-adds of term t
             uint32_t w = tbl[off + lig];
-            uint32_t wn = T > 1 ? tbl[off + LIG + lig] : 0;
+            uint32_t wn = tbl[off + LIG + lig];
             const uint32_t ew = tbl[off + T * LIG + lig];
-            // primary operands are prefetched one term ahead; the (rarer) second operands are fetched at
-            // the top of their term (14 fewer live registers)
             int32_t xa[NL], xb[NL];
             ld(xa, w & 127);
             ld(xb, (w >> 14) & 127);
 #pragma unroll 1
             for (uint32_t t = 0; t < T; t++) {
+                const uint32_t w2 = tbl[off + (t + 2) * LIG + lig];
                 const bool no_a2 = (h3 >> t) & 1, no_b2 = (h3 >> (12 + t)) & 1;   // wave-uniform
                 const bool no_neg = (h1 >> (4 + t)) & 1;                          // no lane negates this term
                 const bool has_da = (h1 >> (16 + t)) & 1;                         // some lane doubles its A operand
@@ -221,16 +223,16 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                     for (int i = 0; i < NL; i++) b[i] = xb[i] + ((x2[i] ^ mb) - mb);
                 }
                 if (t + 1 < T) {
-                    w = wn;
-                    if (t + 2 < T) wn = tbl[off + (t + 2) * LIG + lig];
-                    ld(xa, w & 127);
-                    ld(xb, (w >> 14) & 127);
+                    ld(xa, wn & 127);
+                    ld(xb, (wn >> 14) & 127);
                 }
 #if ZKP_COOP_KARATSUBA
                 acc_mul_k(acc, mid, a, b);
 #else
                 acc_mul(acc, a, b);
 #endif
+                w = wn;
+                wn = w2;
             }
 #if ZKP_COOP_KARATSUBA
             acc_fold(acc, mid);
@@ -1348,7 +1350,8 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     for (int i = 0; i < ZKP_PROG_COUNT; i++) {
         const ZkpProgDesc& p = ZKP_PROGS[i];
         if ((e = hipMalloc((void**)&d->progs[i].hdr, p.n_hdr * 4)) != hipSuccess) return e;
-        if ((e = hipMalloc((void**)&d->progs[i].tbl, p.n_tbl * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&d->progs[i].tbl, (p.n_tbl + 2 * LIG + 4) * 4)) != hipSuccess) return e;
+        if ((e = hipMemset(d->progs[i].tbl, 0, (p.n_tbl + 2 * LIG + 4) * 4)) != hipSuccess) return e;   // the kernel reads table words two terms ahead
         if ((e = hipMemcpy(d->progs[i].hdr, p.hdr, p.n_hdr * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
         if ((e = hipMemcpy(d->progs[i].tbl, p.tbl, p.n_tbl * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
         d->progs[i].nslot = p.nslot;
