@@ -659,6 +659,24 @@ def test_bilinearity_on_gpu(keng):
     assert np.array_equal(lhs[0], o.fp12_pow_u64(o.pairing_batch(o.g1_generator(), o.g2_generator())[0], a * b))
 
 
+def test_gpu_pairing_equals_the_tate_pairing_of_the_definition(keng):
+    """the GPU's Gt against the reduced Tate pairing computed from its definition (tests/golden/tate_definition.py:
+    polynomial Fp12, untwisted Q, Miller loop over r, plain exponentiation) through e = tate^k, k fixed by the
+    Hess-Smart-Vercauteren relation - no oracle, no model in between"""
+    import tate_definition as td
+    from zkvm_pairings_amd import synthetic
+    c, m3 = td.ate_relation_exponents()
+    k = m3 * pow(c, -1, td.R) % td.R
+    g1, g2, _, _ = synthetic.random_pairs(keng, 3, seed=0x7A7E)
+    g1 = np.concatenate([synthetic.G1_GENERATOR.reshape(1, 12), np.asarray(g1)])
+    g2 = np.concatenate([synthetic.G2_GENERATOR.reshape(1, 24), np.asarray(g2)])
+    gt = keng.pairing(g1, g2)
+    for i in range(len(g1)):
+        p1, q = o.arr_to_ints(g1[i]), o.arr_to_ints(g2[i])
+        t = td.tate((q[0], q[1]), (q[2], q[3]), p1[0], p1[1])
+        assert td.from_tower_wire(o.arr_to_ints(gt[i])) == td.f_pow(t, k)
+
+
 def test_device_tensor_api_matches_host_api(keng):
     import torch
     from zkvm_pairings_amd import synthetic

@@ -257,6 +257,38 @@ def test_pairing_properties():
                           o.multi_miller_loop_batch(g1, g2, 1, 1)[0])
 
 
+def _expected_from_tate(p1_ints, q_ints):
+    """e(P, Q) as a power of the reduced Tate pairing computed from its definition (tests/golden/tate_definition.py)"""
+    import tate_definition as td
+    c, m3 = td.ate_relation_exponents()
+    assert c % td.R and m3 % td.R                      # both exponents are units mod r: the relation fixes e completely
+    t = td.tate((q_ints[0], q_ints[1]), (q_ints[2], q_ints[3]), p1_ints[0], p1_ints[1])
+    assert t != td.f_one() and td.f_pow(t, td.R) == td.f_one()
+    return td.f_pow(t, m3 * pow(c, -1, td.R) % td.R)
+
+
+def test_pairing_equals_the_tate_pairing_of_the_definition(model_vectors):
+    """The reference holds no pairing value, so the oracle's e(P, Q) is pinned to the DEFINITION instead:
+    the reduced Tate pairing f_{r,Q}(P)^((p^12-1)/r) from textbook arithmetic that shares nothing with the oracle or the
+    model (Fp12 as plain polynomials mod w^12 - 2 w^6 + 2, untwisted Q, affine chord-and-tangent with polynomial
+    inversions, Miller loop over r, one plain exponentiation), and the Hess-Smart-Vercauteren relation
+    ate^c = tate^((x^12-1)/r), e = ate^3.  Both the C oracle and the big-int model must give exactly that element."""
+    import tate_definition as td
+    cases = [(ints(o.g1_generator()), ints(o.g2_generator()))]
+    cases += [([H(x) for x in c["g1"]], [H(x) for x in c["g2"]]) for c in model_vectors["pairing"]["random"][:2]]
+    rng = Rng(0x7A7E)
+    a, b = rng.fp() % m.R_ORDER, rng.fp() % m.R_ORDER
+    pa, _ = o.g1_mul(o.g1_generator(), a)
+    qb, _ = o.g2_mul(o.g2_generator(), b)
+    cases.append((ints(pa), ints(qb)))
+    for p1, q in cases:
+        want = _expected_from_tate(p1, q)
+        got = o.pairing_batch(o.ints_to_arr(p1), o.ints_to_arr(q))[0]
+        assert td.from_tower_wire(ints(got)) == want
+        mine = m.pairing((p1[0], p1[1]), ((q[0], q[1]), (q[2], q[3])))
+        assert td.from_tower_wire(m.f12_flat_ints(mine)) == want
+
+
 # ------------------------------------------------------------------ seeded Style-1 property tests
 @pytest.mark.parametrize("n,mul,sq,add,sub,neg,inv", [
     (6, o.fp_mul, o.fp_square, o.fp_add, o.fp_sub, o.fp_neg, o.fp_invert),
