@@ -121,17 +121,19 @@ __device__ __forceinline__ void canon28(uint32_t* f, const int32_t* x) {
     for (int i = 0; i < NL; i++) f[i] = (uint32_t)(neg ? z[i] : (ge ? y[i] : u[i]));
 }
 
+__host__ __device__ constexpr int coop_group_stride(int S) { return S + ((4 - S % 8) + 8) % 8; }
+constexpr size_t coop_lds_bytes(int S, int SC) { return (size_t)4 * (SC + GROUPS * coop_group_stride(S)) * 16; }
 #ifndef ZKP_COOP_KARATSUBA
 #define ZKP_COOP_KARATSUBA 1   // acc_mul_k: 147 multiply-adds per product block instead of 196 (zkp_fp28.hpp); measured on one box,
                                // 2^20-pair pass: 296.5 ms -> 283.3 ms
 #endif
 #ifndef ZKP_COOP_WAVES
 #define ZKP_COOP_WAVES 2   // register bound only: the Karatsuba accumulators (80 VGPRs) + prefetched operands need 168 VGPRs = 3 waves
-                           // per SIMD (12 x 10 KB of LDS per CU).  Measured alternatives: bound 3 -> 4 spilled VGPRs, 290.7 ms;
+                           // per SIMD (12 x 11-12 KB of LDS per CU).  Measured alternatives: bound 3 -> 4 spilled VGPRs, 290.7 ms;
                            // bound 4 (128 VGPRs, 86 spilled) -> 925 ms; without Karatsuba 4 waves x 128 VGPRs: 296.5 ms
 #endif
-// S slots per group and SC constants: two instantiations with the same LDS footprint (10,096 B per wavefront) -
-// <24, 34> for programs that need the whole constants table, <30, 4> for the Miller programs (30 slots, 4 constants)
+// S slots per group and SC constants: two instantiations - <24, 34> for programs that need the whole constants table (11,136 B of
+// LDS per wavefront), <30, 4> for the Miller programs (30 slots, 4 constants; 11,776 B); twelve wavefronts per CU either way
 template <int S, int SC>
 __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     extern __shared__ int4 lds[];
@@ -143,10 +145,14 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     const bool active = lane_ok && check < A.n_checks;
     // S, SC: compile-time plane strides (the q * stride offsets fold into the ds_read/ds_write immediates); A.nconst
     // of the SC constants are uploaded
-    const int cbase = 0;
-    const int gbase = 4 * SC + (lane_ok ? grp : GROUPS - 1) * (4 * S + 3);
+    // LDS image: four planes (limb quads) of PS records; a plane holds the SC constants, then SG records per group.  ONE plane
+    // stride for constants and slots: the plane offsets of every ds_read / ds_write are immediates and an operand's address is
+    // (its group's base or 0) + its number.  SG = S rounded up to 4 mod 8: the lane groups of a ds_read_b128 (lanes of up to
+    // three check groups) then fall on different bank quads for neighbouring slots.
+    constexpr int SG = coop_group_stride(S), PS = SC + GROUPS * SG;
+    const int gbase = SC + (lane_ok ? grp : GROUPS - 1) * SG;
 
-    for (int i = lane; i < (int)A.nconst * 4; i += 64) lds[(i & 3) * SC + (i >> 2)] = A.consts[i];
+    for (int i = lane; i < (int)A.nconst * 4; i += 64) lds[(i & 3) * PS + (i >> 2)] = A.consts[i];
     __syncthreads();
 
     // the step headers are read-only and wave-uniform: through the constant address space they become scalar loads
@@ -156,8 +162,8 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     const uint32_t* __restrict__ tbl = A.tbl;
     uint32_t cursor = 0;
     int pc = 0, loop_pc = 0, loop_left = 0;
-    auto slot_off = [&](uint32_t s) -> int { return ((s & 64) ? cbase : gbase) + (int)(s & 63); };
-    auto ld = [&](int32_t* x, uint32_t s) { lds_ld(x, lds, slot_off(s), (s & 64) ? SC : S); };
+    auto slot_off = [&](uint32_t s) -> int { return ((s & 64) ? 0 : gbase) + (int)(s & 63); };
+    auto ld = [&](int32_t* x, uint32_t s) { lds_ld(x, lds, slot_off(s), PS); };
 
     for (;;) {
         const uint32_t h0 = hdr[4 * pc], h1 = hdr[4 * pc + 1], off = hdr[4 * pc + 2];
@@ -251,7 +257,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 for (int i = 0; i < NL; i++) r[i] = al * r[i] + be * e[i] - q * K_PBAL[i];
                 weak_norm(r);
             }
-            if (active && ((ew >> 7) & 1)) lds_st(lds, gbase + (int)(ew & 63), S, r);
+            if (active && ((ew >> 7) & 1)) lds_st(lds, gbase + (int)(ew & 63), PS, r);
             if (h1 & 2) {  // step-uniform: companion store of a squaring run - the even lane of an Fp2 coefficient keeps
                            // x0 + x1, the odd lane x0 - x1, so that the next squaring reads its operand forms ready-made
                 int32_t c2[NL];
@@ -261,7 +267,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                     const int32_t o = __builtin_amdgcn_update_dpp(0, r[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
                     c2[i] = odd ? o - r[i] : r[i] + o;
                 }
-                if (active && ((ew >> 29) & 1)) lds_st(lds, gbase + (int)((ew >> 23) & 63), S, c2);
+                if (active && ((ew >> 29) & 1)) lds_st(lds, gbase + (int)((ew >> 23) & 63), PS, c2);
             }
         } else if (op == OP_LIN) {
             int32_t r[NL];
@@ -279,7 +285,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             weak_norm(r);
             if (h1 & 1) vred(r);   // only where the generator's static value bound asks for it
             const uint32_t ew = tbl[off + arg * LIG + lig];
-            if (active && ((ew >> 7) & 1)) lds_st(lds, gbase + (int)(ew & 63), S, r);
+            if (active && ((ew >> 7) & 1)) lds_st(lds, gbase + (int)(ew & 63), PS, r);
         } else if (op == OP_GLOAD) {
             const uint32_t w = tbl[off + lig];
             const uint32_t idx = w >> 8;
@@ -306,7 +312,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                     x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
                     x[8] = v2.x; x[9] = v2.y; x[10] = v2.z; x[11] = v2.w; x[12] = v3.x; x[13] = v3.y;
                 }
-                lds_st(lds, gbase + (int)(w & 63), S, x);
+                lds_st(lds, gbase + (int)(w & 63), PS, x);
             }
             cursor += h1;
         } else if (op == OP_GSTORE) {
@@ -314,7 +320,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             const uint32_t idx = w >> 8;
             const bool part = active && ((w >> 7) & 1);
             int32_t x[NL];
-            lds_ld(x, lds, gbase + (int)(w & 63), S);
+            lds_ld(x, lds, gbase + (int)(w & 63), PS);
             if (arg == K_STATE) {
                 if (part) {
                     int4* dst = A.state + ((size_t)(idx + A.st_off) * A.nc + check) * 4;
@@ -1451,9 +1457,10 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     a.nconst = d->progs[prog].nconst;
     a.st_off = st_off;
     a.chk_off = chk_off;
-    static_assert(4 * ZKP_COOP_NCONST + GROUPS * (4 * ZKP_COOP_NSLOT + 3) == 4 * ZKP_COOP_WIDE_NCONST + GROUPS * (4 * ZKP_COOP_WIDE_NSLOT + 3),
-                  "both LDS configurations must have the same footprint");
-    size_t lds_bytes = (size_t)(4 * ZKP_COOP_NCONST + GROUPS * (4 * ZKP_COOP_NSLOT + 3)) * 16;
+    const size_t lds_plain = coop_lds_bytes(ZKP_COOP_NSLOT, ZKP_COOP_NCONST), lds_wide = coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST);
+    static_assert(12 * coop_lds_bytes(ZKP_COOP_NSLOT, ZKP_COOP_NCONST) <= 160 * 1024 && 12 * coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST) <= 160 * 1024,
+                  "twelve wavefronts (three per SIMD, the register bound) must fit the 160 KB of LDS of a CU");
+    size_t lds_bytes = wide ? lds_wide : lds_plain;
     static const char* pad_env = getenv("ZKP_COOP_LDS_PAD");   // occupancy experiments only
     if (pad_env) lds_bytes += (size_t)atol(pad_env);
     unsigned blocks = (n_checks + GROUPS - 1) / GROUPS;
