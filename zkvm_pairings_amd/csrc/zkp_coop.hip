@@ -658,34 +658,122 @@ __device__ __forceinline__ Fp28 c_neg(const Fp28& a) {
 
 struct G2C { Fp28 x, y, z; };   // this lane's coefficient of the three Jacobian coordinates
 
+// ---- lazily normalised arithmetic of the doubling step, with its bounds carried in the TYPE: Bd<L, LO, HI> is a value whose
+// limbs are at most L (2^27 + 16) in magnitude and whose value lies in [LO, HI] units of p / 64.  Additions, subtractions and
+// doublings are plain limb-wise operations (no carry pass); every consumer states what it can take as a static_assert, so a
+// formula that would overflow an int32 limb, a 64-bit product column or the value renormalisation does not compile:
+//   * a product column holds 14 * sum(La Lb) * 2^54 < 2^63  =>  sum(La Lb) <= 30 (zkp_fp28.hpp); the operand forms of the
+//     Fp2 squaring double the limb bound (x0 + x1, x0 - x1, 2 x0);
+//   * a Montgomery reduction returns (-0.05 p, 1.05 p) while sum(|a| |b|) <= 100 p^2 (R = 2^392 = 2521 p);
+//   * the one-pass normalisation adds 2^27 to a limb: L <= 14;  the value renormalisation subtracts q p first, q <= |v| / p + 1/2,
+//     p's balanced limbs are at most 2^27: L + q + 1 <= 15.
+template <int L, int LO, int HI> struct Bd { Fp28 v; };
+constexpr int bd_k(int lo, int hi) { return -lo > hi ? -lo : hi; }
+typedef Bd<1, -4, 68> BdRed;     // a reduced product
+typedef Bd<1, -33, 33> BdVred;   // after the value renormalisation (|v| <= 0.51 p)
+template <int L1, int A1, int B1, int L2, int A2, int B2>
+__device__ __forceinline__ Bd<L1 + L2, A1 + A2, B1 + B2> bd_add(const Bd<L1, A1, B1>& a, const Bd<L2, A2, B2>& b) {
+    Bd<L1 + L2, A1 + A2, B1 + B2> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v.l[i] = a.v.l[i] + b.v.l[i];
+    return r;
+}
+template <int L1, int A1, int B1, int L2, int A2, int B2>
+__device__ __forceinline__ Bd<L1 + L2, A1 - B2, B1 - A2> bd_sub(const Bd<L1, A1, B1>& a, const Bd<L2, A2, B2>& b) {
+    Bd<L1 + L2, A1 - B2, B1 - A2> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v.l[i] = a.v.l[i] - b.v.l[i];
+    return r;
+}
+template <int L, int A, int B>
+__device__ __forceinline__ Bd<2 * L, 2 * A, 2 * B> bd_dbl(const Bd<L, A, B>& a) {
+    Bd<2 * L, 2 * A, 2 * B> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v.l[i] = a.v.l[i] + a.v.l[i];
+    return r;
+}
+template <int L, int A, int B>
+__device__ __forceinline__ Bd<L, -B, -A> bd_neg(const Bd<L, A, B>& a) {
+    Bd<L, -B, -A> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v.l[i] = -a.v.l[i];
+    return r;
+}
+template <int L, int A, int B>
+__device__ __forceinline__ Bd<1, A, B> bd_norm(const Bd<L, A, B>& a) {
+    static_assert(L <= 14, "one-pass normalisation: |limb| + 2^27 must stay below 2^31");
+    Bd<1, A, B> r;
+    r.v = a.v;
+    weak_norm(r.v.l);
+    return r;
+}
+template <int L, int A, int B>
+__device__ __forceinline__ BdVred bd_vred(const Bd<L, A, B>& a) {
+    static_assert(L + (bd_k(A, B) + 32 + 63) / 64 + 1 <= 15, "value renormalisation: |limb| + q 2^27 + 2^27 must stay below 2^31");
+    BdVred r;
+    r.v = a.v;
+    vred(r.v.l);
+    return r;
+}
+template <int L, int A, int B>
+__device__ __forceinline__ BdRed bd_sqr(const Bd<L, A, B>& a, int c) {
+    static_assert(4 * L * L <= 30, "column budget of the Fp2 squaring (its operand forms double the limbs)");
+    static_assert(4 * bd_k(A, B) * bd_k(A, B) <= 100 * 64 * 64, "value budget of the reduction");
+    BdRed r;
+    r.v = c_sqr(a.v, c);
+    return r;
+}
+template <int L1, int A1, int B1, int L2, int A2, int B2>
+__device__ __forceinline__ BdRed bd_mul(const Bd<L1, A1, B1>& a, const Bd<L2, A2, B2>& b, int c) {
+    static_assert(2 * L1 * L2 <= 30, "column budget of the Fp2 product (two products per coefficient)");
+    static_assert(2 * bd_k(A1, B1) * bd_k(A2, B2) <= 100 * 64 * 64, "value budget of the reduction");
+    BdRed r;
+    r.v = c_mul(a.v, b.v, c);
+    return r;
+}
+// static checks for values that leave the typed code as plain Fp28
+template <int L, int A, int B>
+__device__ __forceinline__ const Fp28& bd_for_vred(const Bd<L, A, B>& a) {
+    static_assert(L + (bd_k(A, B) + 32 + 63) / 64 + 1 <= 15, "value renormalisation: |limb| + q 2^27 + 2^27 must stay below 2^31");
+    return a.v;
+}
+template <int L, int A, int B>
+__device__ __forceinline__ const Fp28& bd_for_fmul(const Bd<L, A, B>& a) {   // multiplied by a reduced Fp value (limbs <= 2^27, |v| <= 1.05 p)
+    static_assert(L <= 30 && bd_k(A, B) * 68 <= 100 * 64 * 64, "budgets of the Fp product");
+    return a.v;
+}
+
 // ePrint 2010/354 Alg. 26; hands this lane's coefficient of the line (c0, c1, c2) to the three sinks and advances r.
 // The operations are ordered so that few values are live at any call: a by-value call keeps the caller's values in
 // the ~108 callee-saved VGPRs only, everything beyond that is spilled around EVERY call (that was 100 GB of scratch
-// traffic per 2^20 pairs); the line coefficients leave through the sinks as soon as they exist.
+// traffic per 2^20 pairs); the line coefficients leave through the sinks as soon as they exist.  Three one-pass
+// normalisations per step are left (24 when every addition normalised its result): the types prove the rest unnecessary.
+// sink_l2 renormalises its argument; sink_l0 / sink_l1 multiply theirs by a reduced Fp value.
 template <class S0, class S1, class S2>
 __device__ __forceinline__ void dbl_step(G2C& r, int c, S0&& sink_l0, S1&& sink_l1, S2&& sink_l2) {
-    Fp28 zsq = c_sqr(r.z, c);
-    Fp28 nz = c_sqr(c_add(r.z, r.y), c);
-    Fp28 tmp1 = c_sqr(r.y, c);
-    nz = c_sub(c_sub(nz, tmp1), zsq);
-    Fp28 tmp0 = c_sqr(r.x, c);
-    Fp28 tmp4 = c_add(c_add(tmp0, tmp0), tmp0);
-    Fp28 tmp5 = c_sqr(tmp4, c);
+    Bd<1, -33, 68> x, y, z;    // renormalised by the previous step, or a reduced input coordinate (the first step)
+    x.v = r.x; y.v = r.y; z.v = r.z;
+    auto zsq = bd_sqr(z, c);
+    auto nzs = bd_sqr(bd_add(z, y), c);
+    auto tmp1 = bd_sqr(y, c);
+    auto nz = bd_sub(bd_sub(nzs, tmp1), zsq);
+    auto tmp0 = bd_sqr(x, c);
+    auto tmp4 = bd_norm(bd_add(bd_add(tmp0, tmp0), tmp0));
+    auto tmp5 = bd_sqr(tmp4, c);
     {
-        Fp28 tmp6 = c_sqr(c_add(r.x, tmp4), c);
-        tmp6 = c_sub(c_sub(tmp6, tmp0), tmp5);
-        sink_l2(c_sub(tmp6, c_dbl(c_dbl(tmp1))));
+        auto tmp6 = bd_sub(bd_sub(bd_sqr(bd_add(x, tmp4), c), tmp0), tmp5);
+        sink_l2(bd_for_vred(bd_sub(tmp6, bd_dbl(bd_dbl(tmp1)))));
     }
-    Fp28 tmp3 = c_sqr(c_add(tmp1, r.x), c);
-    Fp28 tmp2 = c_sqr(tmp1, c);
-    tmp3 = c_dbl(c_sub(c_sub(tmp3, tmp0), tmp2));
-    sink_l1(c_neg(c_dbl(c_mul(tmp4, zsq, c))));
-    sink_l0(c_dbl(c_mul(nz, zsq, c)));
-    Fp28 nx = c_sub(c_sub(tmp5, tmp3), tmp3);
-    Fp28 ny = c_mul(c_sub(tmp3, nx), tmp4, c);
-    ny = c_sub(ny, c_dbl(c_dbl(c_dbl(tmp2))));
-    vred(nx.l); vred(ny.l); vred(nz.l);
-    r.x = nx; r.y = ny; r.z = nz;
+    auto tmp3s = bd_sqr(bd_add(tmp1, x), c);
+    auto tmp2 = bd_sqr(tmp1, c);
+    auto tmp3 = bd_norm(bd_dbl(bd_sub(bd_sub(tmp3s, tmp0), tmp2)));
+    sink_l1(bd_for_fmul(bd_neg(bd_dbl(bd_mul(tmp4, zsq, c)))));
+    sink_l0(bd_for_fmul(bd_dbl(bd_mul(nz, zsq, c))));
+    auto nx = bd_sub(bd_sub(tmp5, tmp3), tmp3);
+    auto ny = bd_sub(bd_mul(bd_sub(tmp3, nx), tmp4, c), bd_norm(bd_dbl(bd_dbl(bd_dbl(tmp2)))));
+    r.x = bd_vred(nx).v;
+    r.y = bd_vred(ny).v;
+    r.z = bd_vred(nz).v;
 }
 // ePrint 2010/354 Alg. 27
 __device__ __forceinline__ void add_step(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, const Fp28& qx, const Fp28& qy, int c) {
