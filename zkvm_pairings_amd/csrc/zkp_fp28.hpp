@@ -46,11 +46,12 @@ __device__ __forceinline__ void acc_mul(Acc& acc, const int32_t* a, const int32_
 }
 
 // The same columns with one level of Karatsuba over the limb halves (a = a_lo + 2^196 a_hi): a_lo b_lo lands in columns
-// 0..12 and a_hi b_hi in columns 14..26 of the ordinary accumulator (they do not overlap), the middle product
-// (a_lo + a_hi)(b_lo + b_hi) in 13 extra columns shared by every term of a lazy accumulation: 147 multiply-adds and 14
-// additions per product instead of 196.  acc_fold() then adds mid - lo - hi at column 7.  All of it is arithmetic mod 2^64
-// on columns whose TRUE values fit (the budget of acc_mul), so intermediate wrap-around is harmless and the columns,
-// hence every limb downstream, are the very integers acc_mul produces.
+// 0..12 and a_hi b_hi in columns 14..26 of the ordinary accumulator (they do not overlap), the middle product in its
+// subtractive form (a_hi - a_lo)(b_lo - b_hi) = a_lo b_hi + a_hi b_lo - a_lo b_lo - a_hi b_hi in 13 extra columns shared by
+// every term of a lazy accumulation: 147 multiply-adds and 14 subtractions per product instead of 196.  acc_fold() then adds
+// mid + lo + hi at column 7 - additions only (gfx950 has a 64-bit add, v_lshl_add_u64, but no 64-bit subtract).  All of it is
+// arithmetic mod 2^64 on columns whose TRUE values fit (the budget of acc_mul), so intermediate wrap-around is harmless and
+// the columns, hence every limb downstream, are the very integers acc_mul produces.
 constexpr int NH = NL / 2;
 struct AccMid { int64_t c[2 * NH - 1]; };
 __device__ __forceinline__ void mid_zero(AccMid& m) {
@@ -58,21 +59,21 @@ __device__ __forceinline__ void mid_zero(AccMid& m) {
     for (int i = 0; i < 2 * NH - 1; i++) m.c[i] = 0;
 }
 __device__ __forceinline__ void acc_mul_k(Acc& acc, AccMid& mid, const int32_t* a, const int32_t* b) {
-    int32_t sa[NH], sb[NH];
+    int32_t da[NH], db[NH];
 #pragma unroll
-    for (int i = 0; i < NH; i++) { sa[i] = a[i] + a[i + NH]; sb[i] = b[i] + b[i + NH]; }
+    for (int i = 0; i < NH; i++) { da[i] = a[i + NH] - a[i]; db[i] = b[i] - b[i + NH]; }
 #pragma unroll
     for (int i = 0; i < NH; i++)
 #pragma unroll
         for (int j = 0; j < NH; j++) {
             acc.c[i + j] += (int64_t)a[i] * (int64_t)b[j];
             acc.c[NL + i + j] += (int64_t)a[NH + i] * (int64_t)b[NH + j];
-            mid.c[i + j] += (int64_t)sa[i] * (int64_t)sb[j];
+            mid.c[i + j] += (int64_t)da[i] * (int64_t)db[j];
         }
 }
 __device__ __forceinline__ void acc_fold(Acc& acc, AccMid& mid) {
 #pragma unroll
-    for (int k = 0; k < 2 * NH - 1; k++) mid.c[k] -= acc.c[k] + acc.c[NL + k];
+    for (int k = 0; k < 2 * NH - 1; k++) mid.c[k] += acc.c[k] + acc.c[NL + k];
 #pragma unroll
     for (int k = 0; k < 2 * NH - 1; k++) acc.c[NH + k] += mid.c[k];
 }
