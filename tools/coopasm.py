@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""Hand-scheduled gfx950 code of the step interpreter's MULACC step (k_coop, zkp_coop.hip) -> csrc/zkp_coop_mulacc.inc.
+
+The C++ term loop of k_coop costs 201 VALU instructions per term for 147 multiply-adds (28 operand copies, address
+arithmetic, 14 Karatsuba half sums) and its per-step part 432 for 196 (80 accumulator clears, a column-serial reduction);
+every attempt to get a copy-free loop out of the compiler ended in spills or a lost wavefront.  This
+generator emits the step as ONE inline-asm block with pinned registers:
+
+  * two operand register sets (terms alternate), loaded straight by ds_read_b128 - no copies;
+  * LDS addresses come RESOLVED from a per-lane table (built by the host at start-up from the generated step tables:
+    zkp_coop.hip coop_init), so a term has no address arithmetic at all;
+  * the first term's multiply-adds take the inline constant 0 as addend - the 40 accumulator pairs are never cleared;
+  * sign and doubling of the A operand are one v_xad_u32 / v_lshlrev_b32 per limb, only in terms that need them
+    (wave-uniform header bits);
+  * the Montgomery reduction runs row by row, the twelve trailing multiply-adds of row i interleaved behind the
+    m-computation of row i + 1, so the dependent chain (mul_lo, and, mad, shift, add) never stalls the wavefront;
+  * limb extraction is one v_bfe_i32 per limb + the 64-bit carry.
+
+The arithmetic is EXACTLY acc_mul_k / acc_fold / acc_reduce of zkp_fp28.hpp (the same columns mod 2^64, the same m_i, the
+same balanced limbs), so tools/coopgen.py's emulator stays the gate and `ZKP_COOP_ASM=0` builds the C++ loop as the A/B baseline.
+
+Reference anchors (what the step computes): Fp12::mul_by_014 src/fp12.rs:99-111, Fp12::square :173-184, Fp12 Mul :193-210.
+"""
+import os
+import sys
+
+NL, NH = 14, 7
+
+
+class Asm:
+    def __init__(self, vb):
+        self.lines = []
+        self.vb = vb
+        v = vb
+        self.E = v; v += 3            # resolved table entry of the next term: x = A1 address, y = B1 address, z = A2 | B2 << 16
+        self.vz = v; v += 1           # B2 address of a term with two second operands (its A2 is the one that is prefetched)
+        self.F = v; v += 2            # per-step flag words: F1 = neg bits | doubling bits << 12, F2 = a2-sign bits | b2-sign bits << 12
+        self.vm = v; v += 1           # sign mask / shift count / address temporary
+        self.vc = v; v += 1           # -mask
+        assert v % 2 == 0
+        self.D = v; v += 14           # Karatsuba differences / prefetched second operand / tail temporaries
+        self.A = [0, 0]
+        self.B = [0, 0]
+        self.A[0] = v; v += 14
+        self.B[0] = v; v += 14
+        self.A[1] = v; v += 14
+        self.B[1] = v; v += 14
+        self.ACC = {}
+        for k in range(27):
+            if k == 13:
+                continue
+            self.ACC[k] = v; v += 2
+        self.MID = {}
+        for k in range(13):
+            self.MID[k] = v; v += 2
+        self.vend = v
+        # scalars (clobbered)
+        self.sb = 36
+        s = self.sb
+        self.sRT = s; s += 2
+        self.sT = s; s += 2           # loop counter (+ pad: 64-bit scalar operands are even-aligned)
+        self.sX = s; s += 2           # temporaries
+        self.sN = s; s += 2           # number of the next term (+ pad)
+        self.sC = s; s += 2           # carry-out sink of the multiply-adds
+        self.send = s
+
+    def e(self, s):
+        self.lines.append(s)
+
+    def mad(self, dst, a, b, add, signed=True):
+        op = "v_mad_i64_i32" if signed else "v_mad_u64_u32"
+        addt = "0" if add is None else "v[%d:%d]" % (add, add + 1)
+        self.e("%s v[%d:%d], s[%d:%d], %s, %s, %s" % (op, dst, dst + 1, self.sC, self.sC + 1, a, b, addt))
+
+
+def vreg(i):
+    return "v%d" % i
+
+
+def ds_read_rec(g, dst, addr):
+    """record (four planes of limb quads) at LDS byte address in VGPR addr -> 14 registers from dst"""
+    g.e("ds_read_b128 v[%d:%d], %s" % (dst, dst + 3, addr))
+    g.e("ds_read_b128 v[%d:%d], %s offset:%%[ps1]" % (dst + 4, dst + 7, addr))
+    g.e("ds_read_b128 v[%d:%d], %s offset:%%[ps2]" % (dst + 8, dst + 11, addr))
+    g.e("ds_read_b64 v[%d:%d], %s offset:%%[ps3]" % (dst + 12, dst + 13, addr))
+
+
+def second_fetch(g, L, nbit):
+    """request the second operand of the term whose header bits are (h3 >> nbit) from the entry in E: its A2 record if it has
+    one (the B2 address is then parked in vz), else its B2 record, into D.  Called where D is free: in the prologue and behind
+    a term's middle product."""
+    g.e("s_lshr_b32 s%d, %%[h3], s%d" % (g.sX, nbit))
+    g.e("s_and_b32 s%d, s%d, 0x1001" % (g.sX + 1, g.sX))
+    g.e("s_cmp_eq_u32 s%d, 0x1001" % (g.sX + 1))
+    g.e("s_cbranch_scc1 %s_nosf" % L)
+    g.e("s_bitcmp1_b32 s%d, 0" % g.sX)
+    g.e("s_cbranch_scc1 %s_sfb" % L)
+    g.e("v_and_b32 v%d, 0xffff, v%d" % (g.vm, g.E + 2))
+    g.e("v_lshrrev_b32 v%d, 16, v%d" % (g.vz, g.E + 2))
+    g.e("s_branch %s_sfgo" % L)
+    g.e("%s_sfb:" % L)
+    g.e("v_lshrrev_b32 v%d, 16, v%d" % (g.vm, g.E + 2))
+    g.e("%s_sfgo:" % L)
+    ds_read_rec(g, g.D, vreg(g.vm))
+    g.e("%s_nosf:" % L)
+
+
+def add_signed(g, X, bit):
+    """X[i] += +-D[i]: the lane's sign is bit `bit` (a scalar register) of flag word F2"""
+    g.e("v_bfe_i32 v%d, v%d, s%d, 1" % (g.vm, g.F + 1, bit))
+    g.e("v_sub_u32 v%d, 0, v%d" % (g.vc, g.vm))
+    for i in range(NL):
+        g.e("v_xad_u32 v%d, v%d, v%d, v%d" % (X + i, g.D + i, g.vm, X + i))
+    for i in range(NL):
+        g.e("v_add_u32 v%d, v%d, v%d" % (X + i, X + i, g.vc))
+
+
+def term(g, p, first, tag):
+    """one term on operand set p; its operands (and its A2, or else B2, record in D) were requested during the previous term"""
+    A, B, D = g.A[p], g.B[p], g.D
+    L = ".Lm%s_%%=" % tag
+    g.e("s_waitcnt lgkmcnt(0)")
+    # ---- operand forming (wave-uniform header bits; st = term number)
+    # second operands: h3 bit st = no A2, bit 12 + st = no B2
+    g.e("s_lshr_b32 s%d, %%[h3], s%d" % (g.sX, g.sT))
+    g.e("s_and_b32 s%d, s%d, 0x1001" % (g.sX + 1, g.sX))
+    g.e("s_cmp_eq_u32 s%d, 0x1001" % (g.sX + 1))
+    g.e("s_cbranch_scc1 %s_nosec" % L)
+    g.e("s_bitcmp1_b32 s%d, 0" % g.sX)
+    g.e("s_cbranch_scc1 %s_noa2" % L)
+    add_signed(g, A, g.sT)
+    g.e("s_bitcmp1_b32 s%d, 12" % g.sX)
+    g.e("s_cbranch_scc1 %s_nosec" % L)
+    ds_read_rec(g, D, vreg(g.vz))          # both second operands: B2 on demand
+    g.e("s_waitcnt lgkmcnt(0)")
+    g.e("%s_noa2:" % L)
+    g.e("s_add_u32 s%d, s%d, 12" % (g.sX + 1, g.sT))
+    add_signed(g, B, g.sX + 1)
+    g.e("%s_nosec:" % L)
+    # sign of the product (h1 bit 4 + st set = no lane negates) and doubled A operand (h1 bit 16 + st = some lane doubles)
+    g.e("s_lshr_b32 s%d, %%[h1], s%d" % (g.sX, g.sT))
+    g.e("s_bitcmp1_b32 s%d, 4" % g.sX)
+    g.e("s_cbranch_scc1 %s_noneg" % L)
+    g.e("v_bfe_i32 v%d, v%d, s%d, 1" % (g.vm, g.F, g.sT))
+    g.e("v_sub_u32 v%d, 0, v%d" % (g.vc, g.vm))
+    for i in range(NL):
+        g.e("v_xad_u32 v%d, v%d, v%d, v%d" % (A + i, A + i, g.vm, g.vc))
+    g.e("%s_noneg:" % L)
+    g.e("s_bitcmp1_b32 s%d, 16" % g.sX)
+    g.e("s_cbranch_scc0 %s_noda" % L)
+    g.e("s_add_u32 s%d, s%d, 12" % (g.sX + 1, g.sT))
+    g.e("v_bfe_u32 v%d, v%d, s%d, 1" % (g.vm, g.F, g.sX + 1))
+    for i in range(NL):
+        g.e("v_lshlrev_b32 v%d, v%d, v%d" % (A + i, g.vm, A + i))
+    g.e("%s_noda:" % L)
+    # ---- first operands of the next term into the other set
+    g.e("s_add_u32 s%d, s%d, 1" % (g.sN, g.sT))
+    g.e("s_cmp_ge_u32 s%d, %%[T]" % g.sN)
+    g.e("s_cbranch_scc1 %s_nopre" % L)
+    g.e("s_waitcnt vmcnt(0)")
+    ds_read_rec(g, g.A[1 - p], vreg(g.E))
+    ds_read_rec(g, g.B[1 - p], vreg(g.E + 1))
+    g.e("%s_nopre:" % L)
+    # ---- Karatsuba differences: D[i] = a_hi - a_lo, D[7 + i] = b_lo - b_hi
+    for i in range(NH):
+        g.e("v_sub_u32 v%d, v%d, v%d" % (D + i, A + NH + i, A + i))
+    for i in range(NH):
+        g.e("v_sub_u32 v%d, v%d, v%d" % (D + NH + i, B + i, B + NH + i))
+    # ---- 147 multiply-adds: lo -> columns 0..12, hi -> 14..26, middle -> its own 13 columns.  The middle product goes first:
+    # behind it D is free again and takes the next term's second operand while the other 98 multiply-adds run.
+    touched = set()
+
+    def acc(reg_key, dst, a, b):
+        add = dst
+        if first and reg_key not in touched:
+            add = None
+            touched.add(reg_key)
+        g.mad(dst, vreg(a), vreg(b), add)
+
+    for j in range(NH):
+        for i in range(NH):
+            acc(("m", i + j), g.MID[i + j], D + i, D + NH + j)
+    g.e("s_cmp_ge_u32 s%d, %%[T]" % g.sN)
+    g.e("s_cbranch_scc1 %s_nopre2" % L)
+    second_fetch(g, L, g.sN)
+    g.e("s_add_u32 s%d, s%d, 0x400" % (g.sRT, g.sRT))
+    g.e("s_addc_u32 s%d, s%d, 0" % (g.sRT + 1, g.sRT + 1))
+    g.e("global_load_dwordx3 v[%d:%d], %%[lane16], s[%d:%d] offset:1024" % (g.E, g.E + 2, g.sRT, g.sRT + 1))
+    g.e("%s_nopre2:" % L)
+    for j in range(NH):
+        for i in range(NH):
+            acc(("a", i + j), g.ACC[i + j], A + i, B + j)
+            acc(("a", NL + i + j), g.ACC[NL + i + j], A + NH + i, B + NH + j)
+
+
+def tail(g, out):
+    """fold, Montgomery reduction, limb extraction -> 14 registers from out"""
+    D = g.D
+    col = dict(g.ACC)
+    # fold: mid[k] += lo[k] + hi[k]; column 7 + k += mid[k]  (column 13 has no product of its own: it IS mid[6])
+    for k in range(13):
+        g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (g.MID[k], g.MID[k] + 1, g.MID[k], g.MID[k] + 1, g.ACC[k], g.ACC[k] + 1))
+    for k in range(13):
+        g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (g.MID[k], g.MID[k] + 1, g.MID[k], g.MID[k] + 1, g.ACC[NL + k], g.ACC[NL + k] + 1))
+    col[13] = g.MID[6]
+    for k in range(13):
+        if k == 6:
+            continue
+        c = col[NH + k]
+        g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (c, c + 1, c, c + 1, g.MID[k], g.MID[k] + 1))
+    # reduction, row i: m = (low word of column i * PINV) mod 2^28; column i + j += m p_j; column i + 1 += column i >> 28.
+    # Emission order per row: m, the j = 0 and j = 1 products, the carry - then the twelve remaining products of the
+    # PREVIOUS row fill the latency of the next row's m.
+    mreg = [D + 0, D + 1]
+    tmp = D + 2   # pair (even-aligned: D is even)
+    assert tmp % 2 == 0
+
+    def rest(i):
+        """the products j = 2..13 of row i as a list of instructions"""
+        r = []
+        for j in range(2, NL):
+            c = col[i + j]
+            r.append("v_mad_u64_u32 v[%d:%d], s[%d:%d], v%d, %%[p%d], v[%d:%d]" % (c, c + 1, g.sC, g.sC + 1, mreg[i & 1], j, c, c + 1))
+        return r
+
+    for i in range(NL):
+        m = mreg[i & 1]
+        c0, c1 = col[i], col[i + 1]
+        # the dependent chain of row i (mul_lo, and, mad, shift, add) with the previous row's products in its gaps
+        R = rest(i - 1) if i > 0 else []
+        fill = [R[0:3], R[3:6], R[6:9], R[9:12]] if R else [[], [], [], []]
+        g.e("v_mul_lo_u32 v%d, v%d, %%[pinv]" % (m, c0))
+        for x in fill[0]:
+            g.e(x)
+        g.e("v_and_b32 v%d, 0xfffffff, v%d" % (m, m))
+        for x in fill[1]:
+            g.e(x)
+        g.e("v_mad_u64_u32 v[%d:%d], s[%d:%d], v%d, %%[p0], v[%d:%d]" % (c0, c0 + 1, g.sC, g.sC + 1, m, c0, c0 + 1))
+        g.e("v_mad_u64_u32 v[%d:%d], s[%d:%d], v%d, %%[p1], v[%d:%d]" % (c1, c1 + 1, g.sC, g.sC + 1, m, c1, c1 + 1))
+        for x in fill[2]:
+            g.e(x)
+        g.e("v_ashrrev_i64 v[%d:%d], 28, v[%d:%d]" % (tmp, tmp + 1, c0, c0 + 1))
+        for x in fill[3]:
+            g.e(x)
+        g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (c1, c1 + 1, c1, c1 + 1, tmp, tmp + 1))
+    for x in rest(NL - 1):
+        g.e(x)
+    # limb extraction: t = column 14; limb k = sign-extended low 28 bits of t; t = column 15 + k + ((t + 2^27) >> 28)
+    k27 = D + 4
+    g.e("v_mov_b32 v%d, 0x8000000" % k27)
+    g.e("v_mov_b32 v%d, 0" % (k27 + 1))
+    t = col[NL]
+    for k in range(NL - 1):
+        g.e("v_bfe_i32 v%d, v%d, 0, 28" % (out + k, t))
+        g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (tmp, tmp + 1, t, t + 1, k27, k27 + 1))
+        g.e("v_ashrrev_i64 v[%d:%d], 28, v[%d:%d]" % (tmp, tmp + 1, tmp, tmp + 1))
+        if k + 1 < NL - 1:
+            nxt = col[NL + k + 1]
+            g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (nxt, nxt + 1, nxt, nxt + 1, tmp, tmp + 1))
+            t = nxt
+        else:
+            g.e("v_mov_b32 v%d, v%d" % (out + NL - 1, tmp))    # column 27 is empty: the last carry is the top limb
+
+
+def generate(vb=8):
+    g = Asm(vb)
+    out = g.A[0]
+    # prologue: per-step flag words (row T of the resolved table), entry of term 0, operands of term 0, entry of term 1
+    g.e("s_mov_b64 s[%d:%d], %%[rt]" % (g.sRT, g.sRT + 1))
+    g.e("s_lshl_b32 s%d, %%[T], 10" % g.sX)
+    g.e("s_add_u32 s%d, s%d, s%d" % (g.sX, g.sRT, g.sX))
+    g.e("s_addc_u32 s%d, s%d, 0" % (g.sX + 1, g.sRT + 1))
+    g.e("global_load_dwordx3 v[%d:%d], %%[lane16], s[%d:%d]" % (g.E, g.E + 2, g.sRT, g.sRT + 1))
+    g.e("global_load_dwordx2 v[%d:%d], %%[lane16], s[%d:%d]" % (g.F, g.F + 1, g.sX, g.sX + 1))
+    g.e("s_mov_b32 s%d, 0" % g.sT)
+    g.e("s_waitcnt vmcnt(0)")        # the flag words too: the first term's operand forming reads them
+    ds_read_rec(g, g.A[0], vreg(g.E))
+    ds_read_rec(g, g.B[0], vreg(g.E + 1))
+    second_fetch(g, ".Lmp_%=", g.sT)
+    g.e("global_load_dwordx3 v[%d:%d], %%[lane16], s[%d:%d] offset:1024" % (g.E, g.E + 2, g.sRT, g.sRT + 1))
+    term(g, 0, True, "a")
+    g.e("s_add_u32 s%d, s%d, 1" % (g.sT, g.sT))
+    g.e("s_cmp_ge_u32 s%d, %%[T]" % g.sT)
+    g.e("s_cbranch_scc1 .Lmtail_%=")
+    g.e(".Lmloop_%=:")
+    term(g, 1, False, "b")
+    g.e("s_add_u32 s%d, s%d, 1" % (g.sT, g.sT))
+    g.e("s_cmp_ge_u32 s%d, %%[T]" % g.sT)
+    g.e("s_cbranch_scc1 .Lmtail_%=")
+    term(g, 0, False, "c")
+    g.e("s_add_u32 s%d, s%d, 1" % (g.sT, g.sT))
+    g.e("s_cmp_lt_u32 s%d, %%[T]" % g.sT)
+    g.e("s_cbranch_scc1 .Lmloop_%=")
+    g.e(".Lmtail_%=:")
+    g.e("s_waitcnt vmcnt(0)")        # nothing of this block may still be in flight when the compiler's code resumes
+    tail(g, out)
+    g.e("s_waitcnt lgkmcnt(0)")
+    return g, out
+
+
+def write_inc(path, vb=8):
+    g, out = generate(vb)
+    outs = list(range(out, out + NL))
+    vclob = [v for v in range(g.vb, g.vend) if v not in outs]
+    sclob = list(range(g.sb, g.send))
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/coopasm.py - do not edit.  The MULACC step of k_coop as one hand-scheduled inline-asm block.\n")
+        f.write("// %d instructions; VGPRs v%d..v%d, SGPRs s%d..s%d.\n" % (sum(1 for l in g.lines if not l.endswith(":")), g.vb, g.vend - 1, g.sb, g.send - 1))
+        f.write("#pragma once\n")
+        f.write("#define ZKP_MULACC_VGPR_FIRST %d\n#define ZKP_MULACC_VGPR_END %d\n" % (g.vb, g.vend))
+        f.write("#define ZKP_MULACC_ASM \\\n")
+        for l in g.lines:
+            f.write('    "%s\\n\\t" \\\n' % l)
+        f.write('    ""\n')
+        f.write("#define ZKP_MULACC_OUTS(r) " + ", ".join('"={v%d}"((r)[%d])' % (outs[i], i) for i in range(NL)) + "\n")
+        f.write("#define ZKP_MULACC_CLOBBERS " + ", ".join('"v%d"' % v for v in vclob) + ", " + ", ".join('"s%d"' % s for s in sclob) + ', "scc", "memory"\n')
+    return g
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "zkvm_pairings_amd", "csrc", "zkp_coop_mulacc.inc")
+    g = write_inc(path)
+    n = sum(1 for l in g.lines if not l.endswith(":"))
+    print("wrote %s: %d instructions, v%d..v%d" % (path, n, g.vb, g.vend - 1))

@@ -1554,9 +1554,10 @@ def prog_tower_from_snap():
     return b
 
 
-def prog_timing(T, epi, nloop=400, lin=False):
+def prog_timing(T, epi, nloop=400, lin=False, forms="ab"):
     """synthetic timing program (not a meaningful computation): LOOP nloop { MULACC with T two-term products
-    per lane (+ epilogue) } or { LIN with 3 terms }"""
+    per lane (+ epilogue) } or { LIN with 3 terms }.  forms: "ab" both operands are two-slot forms, "b" only the B operand
+    (the shape of the Fp12 products of the final exponentiation), "s" one-slot operands (the shape of the Miller loop's steps)"""
     b = Builder()
     v = b.alloc(12)
     w = b.alloc(12)
@@ -1568,7 +1569,9 @@ def prog_timing(T, epi, nloop=400, lin=False):
     else:
         outs = []
         for i in range(12):
-            bil = Bil([(Lin({v[(i + t) % 12]: 1, w[(i + t + 3) % 12]: 1}), Lin({w[(i + 2 * t) % 12]: 1, v[(i + t + 7) % 12]: -1}), 1) for t in range(T)])
+            fa = lambda t: Lin({v[(i + t) % 12]: 1, w[(i + t + 3) % 12]: 1}) if forms == "ab" else Lin({v[(i + t) % 12]: 1})
+            fb = lambda t: Lin({w[(i + 2 * t) % 12]: 1, v[(i + t + 7) % 12]: -1 if (forms == "ab" or (i + t) % 2) else 1}) if forms in ("ab", "b") else Lin({w[(i + 2 * t) % 12]: 1})
+            bil = Bil([(fa(t), fb(t), 1) for t in range(T)])
             o = {"dst": v[i], "bil": bil}
             if epi:
                 o.update(alpha=3, beta=-2, e=v[i])
@@ -1645,6 +1648,9 @@ PROGRAMS = {
     "time_t6": lambda: prog_timing(6, False),
     "time_t12": lambda: prog_timing(12, False),
     "time_lin": lambda: prog_timing(0, False, lin=True),
+    "time_t6s": lambda: prog_timing(6, False, forms="s"),
+    "time_t12s": lambda: prog_timing(12, False, forms="s"),
+    "time_t12b": lambda: prog_timing(12, False, forms="b"),
     "time_cyc": lambda: prog_timing_cyc(False),
     "time_cycsd": lambda: prog_timing_cyc(True),
     "time_fill": prog_timing_fill,

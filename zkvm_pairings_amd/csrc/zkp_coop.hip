@@ -32,9 +32,17 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "zkp_coop_prog.inc"
 #include "zkp_fp28.hpp"
+#ifndef ZKP_COOP_ASM
+#define ZKP_COOP_ASM 1   // the MULACC step of k_coop as one hand-scheduled inline-asm block (tools/coopasm.py -> zkp_coop_mulacc.inc);
+                         // 0 builds the C++ term loop below it, the A/B baseline
+#endif
+#if ZKP_COOP_ASM
+#include "zkp_coop_mulacc.inc"
+#endif
 
 using namespace zkp28;
 
@@ -53,6 +61,8 @@ __device__ __constant__ const int32_t K_PBAL[NL] = {ZKP_COOP_P_BAL};
 struct CoopArgs {
     const uint32_t* hdr;
     const uint32_t* tbl;
+    const uint4* rtbl;       // resolved MULACC table: row (table offset / 12 + term) x 64 lanes of {A1 address, B1 address, A2 | B2 << 16, 0};
+                             // the row behind a step's terms holds its per-lane flag words (coop_resolve_table)
     const int4* consts;      // NCONST records of 4 int4
     const int4* lines;       // [(step * k + pair) * 6 + c][check] records of 4 int4
     int4* state;             // [elem][check] records of 4 int4
@@ -128,9 +138,14 @@ constexpr size_t coop_lds_bytes(int S, int SC) { return (size_t)4 * (SC + GROUPS
                                // 2^20-pair pass: 296.5 ms -> 283.3 ms
 #endif
 #ifndef ZKP_COOP_WAVES
-#define ZKP_COOP_WAVES 2   // register bound only: the Karatsuba accumulators (80 VGPRs) + prefetched operands need 168 VGPRs = 3 waves
-                           // per SIMD (12 x 11-12 KB of LDS per CU).  Measured alternatives: bound 3 -> 4 spilled VGPRs, 290.7 ms;
-                           // bound 4 (128 VGPRs, 86 spilled) -> 925 ms; without Karatsuba 4 waves x 128 VGPRs: 296.5 ms
+#if ZKP_COOP_ASM
+#define ZKP_COOP_WAVES 3   // the asm block pins 156 VGPRs (80 Karatsuba accumulators, two operand sets); with the per-lane context
+                           // re-derived per step the kernel needs 166 = 3 waves per SIMD, no spills (12 x 11-12 KB of LDS per CU)
+#else
+#define ZKP_COOP_WAVES 2   // C++ term loop: register bound only - it allocates 168 VGPRs = 3 waves per SIMD under bound 2.  Measured
+                           // alternatives: bound 3 -> 4 spilled VGPRs, 290.7 ms; bound 4 (128 VGPRs, 86 spilled) -> 925 ms; without
+                           // Karatsuba 4 waves x 128 VGPRs: 296.5 ms
+#endif
 #endif
 // S slots per group and SC constants: two instantiations - <24, 34> for programs that need the whole constants table (11,136 B of
 // LDS per wavefront), <30, 4> for the Miller programs (30 slots, 4 constants; 11,776 B); twelve wavefronts per CU either way
@@ -138,11 +153,12 @@ template <int S, int SC>
 __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     extern __shared__ int4 lds[];
     const int lane = threadIdx.x;
-    const int grp = (lane * 43) >> 9;          // lane / 12 for lane < 64
-    const int lig = lane - grp * LIG;          // lanes 60..63: grp 5, lig 0..3 (never store)
-    const bool lane_ok = grp < GROUPS;
-    const uint32_t check = blockIdx.x * GROUPS + grp;
-    const bool active = lane_ok && check < A.n_checks;
+    // per-lane values, all functions of the lane number.  With the asm MULACC block (ZKP_COOP_ASM) they are re-derived at the top of
+    // every step and again behind the block from an opaque copy of `lane` (ZKP_LANE_CTX): kept in registers across the block they
+    // would cost the kernel its third wavefront per SIMD (the block owns 156 of the 168 VGPRs)
+    int grp, lig, gbase;
+    uint32_t check;
+    bool lane_ok, active;
     // S, SC: compile-time plane strides (the q * stride offsets fold into the ds_read/ds_write immediates); A.nconst
     // of the SC constants are uploaded
     // LDS image: four planes (limb quads) of PS records; a plane holds the SC constants, then SG records per group.  ONE plane
@@ -150,7 +166,22 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     // (its group's base or 0) + its number.  SG = S rounded up to 4 mod 8: the lane groups of a ds_read_b128 (lanes of up to
     // three check groups) then fall on different bank quads for neighbouring slots.
     constexpr int SG = coop_group_stride(S), PS = SC + GROUPS * SG;
-    const int gbase = SC + (lane_ok ? grp : GROUPS - 1) * SG;
+#if ZKP_COOP_ASM
+#define ZKP_LANE_OPAQUE(l) asm volatile("" : "+v"(l))
+#else
+#define ZKP_LANE_OPAQUE(l) (void)0
+#endif
+#define ZKP_LANE_CTX()                                                                                  \
+    do {                                                                                                \
+        int l_ = lane;                                                                                  \
+        ZKP_LANE_OPAQUE(l_);                                                                            \
+        grp = (l_ * 43) >> 9;             /* lane / 12 for lane < 64 */                                 \
+        lig = l_ - grp * LIG;             /* lanes 60..63: grp 5, lig 0..3 (never store) */             \
+        lane_ok = grp < GROUPS;                                                                         \
+        check = blockIdx.x * GROUPS + grp;                                                              \
+        active = lane_ok && check < A.n_checks;                                                         \
+        gbase = SC + (lane_ok ? grp : GROUPS - 1) * SG;                                                 \
+    } while (0)
 
     for (int i = lane; i < (int)A.nconst * 4; i += 64) lds[(i & 3) * PS + (i >> 2)] = A.consts[i];
     __syncthreads();
@@ -169,11 +200,33 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
         const uint32_t h0 = hdr[4 * pc], h1 = hdr[4 * pc + 1], off = hdr[4 * pc + 2];
         const uint32_t op = h0 & 0xff, arg = (h0 >> 8) & 0xff;
         if (op == OP_END) break;
+        ZKP_LANE_CTX();
         if (op == OP_MULACC) {
             // software pipeline: table words two terms ahead, LDS operands one term ahead, so the
             // 196 multiply-adds of term t cover the latency of everything term t+1 needs
             const uint32_t h3 = hdr[4 * pc + 3];
             const uint32_t T = arg;
+#if ZKP_COOP_ASM
+            // one inline-asm block (tools/coopasm.py): term loop on two operand register sets with resolved per-lane LDS
+            // addresses, Karatsuba fold, row-pipelined Montgomery reduction, limb extraction; the same integers as
+            // acc_mul_k / acc_fold / acc_reduce of the C++ variant below
+            const uint32_t ew = tbl[off + T * LIG + lig];
+            const uint4* rt = A.rtbl + (size_t)(off / LIG) * 64;
+            int32_t r[NL];
+            {
+                static_assert(NL == 14, "the generated block is for 14 limbs");
+                constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};
+                asm volatile(ZKP_MULACC_ASM
+                             : ZKP_MULACC_OUTS(r)
+                             : [rt] "s"(rt), [T] "s"(T), [h1] "s"(h1), [h3] "s"(h3), [lane16] "v"(lane * 16),   // (rematerialised from the lane number: not a live value)
+                               [ps1] "i"(PS * 16), [ps2] "i"(PS * 32), [ps3] "i"(PS * 48),
+                               [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]), [p6] "s"(PL[6]),
+                               [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]), [p12] "s"(PL[12]),
+                               [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)
+                             : ZKP_MULACC_CLOBBERS);
+            }
+            ZKP_LANE_CTX();
+#else
             Acc acc;
             acc_zero(acc);
 #if ZKP_COOP_KARATSUBA
@@ -245,6 +298,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
 #endif
             int32_t r[NL];
             acc_reduce(r, acc);
+#endif
             if (h1 & 1) {  // step-uniform: epilogue dst = alpha r + beta E, renormalised
                 int32_t e[NL];
                 ld(e, (ew >> 16) & 127);
@@ -546,7 +600,7 @@ __global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t
         int32_t pr[NL], pi[NL];
 #pragma unroll
         for (int i = 0; i < NL; i++) { pr[i] = ZKP_QUAD(sre[i], 0xB1); pi[i] = ZKP_QUAD(sim[i], 0xB1); }   // quad_perm [1,0,3,2]
-        if ((snap_mask >> it) & 1) {      // wave-uniform
+        if (it < 64 && ((snap_mask >> it) & 1)) {      // wave-uniform (a 64-bit shift by 64 or more is undefined)
             if (active && !b_lane) {      // lane 0 holds (v, u) = (mine, partner), lane 2 (u, v)
                 Fp28 o;
 #pragma unroll
@@ -1410,7 +1464,7 @@ __global__ void k_fp28_op(int op, const uint64_t* a, const uint64_t* b, size_t n
 // =============================================================================== host side
 namespace zkp {
 
-struct CoopProgDev { uint32_t* hdr; uint32_t* tbl; uint32_t nslot; uint32_t nconst; uint32_t wide; };
+struct CoopProgDev { uint32_t* hdr; uint32_t* tbl; uint4* rtbl; uint32_t nslot; uint32_t nconst; uint32_t wide; };
 constexpr int MAX_PIPES = 4;
 struct CoopPipe {            // one in-flight chunk: its own workspace and (for pipes > 0) its own stream
     int4* lines;  size_t lines_bytes;
@@ -1435,6 +1489,37 @@ struct CoopDev {
     hipEvent_t ready;
 };
 
+// The MULACC table of a program with every LDS address resolved per LANE (the asm block of k_coop reads it: no address
+// arithmetic in the term loop).  Row r = table offset / 12 + term, 64 lanes per row, one uint4 per lane:
+//   x = byte address of the A1 record (plane 0), y = B1, z = A2 | B2 << 16, w = 0;
+// the row behind a step's last term carries the step's per-lane flag words: x = negate bits (bit t = term t) | doubled-A
+// bits << 12, y = subtract-A2 bits | subtract-B2 bits << 12.  Lane -> (group, lane in group) and the slot -> address map are
+// k_coop's (gbase, slot_off); lanes 60..63 compute on group 4's addresses and never store.
+static void coop_resolve_table(const ZkpProgDesc& p, std::vector<uint4>& rt) {
+    const int S = p.wide ? ZKP_COOP_WIDE_NSLOT : ZKP_COOP_NSLOT, SC = p.wide ? ZKP_COOP_WIDE_NCONST : ZKP_COOP_NCONST;
+    const int SG = coop_group_stride(S);
+    const size_t rows = p.n_tbl / LIG + 2;
+    rt.assign(rows * 64, make_uint4(0, 0, 0, 0));
+    auto addr = [&](uint32_t slot, int grp) -> uint32_t { return 16u * (((slot & 64) ? 0 : SC + grp * SG) + (slot & 63)); };
+    for (uint32_t pc = 0; pc * 4 + 3 < p.n_hdr; pc++) {
+        const uint32_t h0 = p.hdr[4 * pc], off = p.hdr[4 * pc + 2];
+        if ((h0 & 0xff) != OP_MULACC) continue;
+        const uint32_t T = (h0 >> 8) & 0xff;
+        for (int lane = 0; lane < 64; lane++) {
+            const int g0 = lane / LIG, lig = lane - g0 * LIG, grp = g0 < GROUPS ? g0 : GROUPS - 1;
+            uint32_t f1 = 0, f2 = 0;
+            for (uint32_t t = 0; t < T; t++) {
+                const uint32_t w = p.tbl[off + t * LIG + lig];
+                rt[(off / LIG + t) * 64 + lane] =
+                    make_uint4(addr(w & 127, grp), addr((w >> 14) & 127, grp), addr((w >> 7) & 127, grp) | (addr((w >> 21) & 127, grp) << 16), 0);
+                f1 |= ((w >> 30) & 1) << t | ((w >> 31) & 1) << (12 + t);
+                f2 |= ((w >> 28) & 1) << t | ((w >> 29) & 1) << (12 + t);
+            }
+            rt[(off / LIG + T) * 64 + lane] = make_uint4(f1, f2, 0, 0);
+        }
+    }
+}
+
 hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     st->cus = prop.multiProcessorCount;
     CoopDev* d = new CoopDev();
@@ -1451,6 +1536,10 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
         d->progs[i].nslot = p.nslot;
         d->progs[i].nconst = p.nconst;
         d->progs[i].wide = p.wide;
+        std::vector<uint4> rt;
+        coop_resolve_table(p, rt);
+        if ((e = hipMalloc((void**)&d->progs[i].rtbl, rt.size() * sizeof(uint4))) != hipSuccess) return e;
+        if ((e = hipMemcpy(d->progs[i].rtbl, rt.data(), rt.size() * sizeof(uint4), hipMemcpyHostToDevice)) != hipSuccess) return e;
     }
     if ((e = hipMalloc((void**)&d->consts, sizeof(ZKP_COOP_CONSTS))) != hipSuccess) return e;
     if ((e = hipMemcpy(d->consts, ZKP_COOP_CONSTS, sizeof(ZKP_COOP_CONSTS), hipMemcpyHostToDevice)) != hipSuccess) return e;
@@ -1495,6 +1584,7 @@ void coop_free(CoopState* st) {
     for (int i = 0; i < ZKP_PROG_COUNT; i++) {
         if (d->progs[i].hdr) (void)hipFree(d->progs[i].hdr);
         if (d->progs[i].tbl) (void)hipFree(d->progs[i].tbl);
+        if (d->progs[i].rtbl) (void)hipFree(d->progs[i].rtbl);
     }
     if (d->consts) (void)hipFree(d->consts);
     if (d->big_state) (void)hipFree(d->big_state);
@@ -1527,6 +1617,7 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     CoopArgs a;
     a.hdr = d->progs[prog].hdr;
     a.tbl = d->progs[prog].tbl;
+    a.rtbl = d->progs[prog].rtbl;
     a.consts = d->consts;
     a.lines = pp->lines;
     a.state = pp->state;
@@ -1545,6 +1636,7 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     a.nconst = d->progs[prog].nconst;
     a.st_off = st_off;
     a.chk_off = chk_off;
+
     const size_t lds_plain = coop_lds_bytes(ZKP_COOP_NSLOT, ZKP_COOP_NCONST), lds_wide = coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST);
     static_assert(12 * coop_lds_bytes(ZKP_COOP_NSLOT, ZKP_COOP_NCONST) <= 160 * 1024 && 12 * coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST) <= 160 * 1024,
                   "twelve wavefronts (three per SIMD, the register bound) must fit the 160 KB of LDS of a CU");
@@ -1663,6 +1755,7 @@ hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, co
 static hipError_t run_ksq(hipStream_t s, int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_in, uint32_t elem_snap, uint32_t nsq,
                           uint64_t snap_mask) {
     if (!n_checks || !nsq) return hipSuccess;
+    if (snap_mask && nsq > 64) return hipErrorInvalidValue;   // snapshot bits exist for the first 64 squarings only
     hipLaunchKernelGGL(k_ksq, dim3((n_checks + KS_CHECKS - 1) / KS_CHECKS), dim3(64), 0, s, state, n_checks, nc, elem_in, elem_snap, nsq, snap_mask);
     return hipGetLastError();
 }
@@ -1822,14 +1915,16 @@ hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, hip
     CoopDev* d = (CoopDev*)st->d_prog;
     static const int ids[9] = {ZKP_PROG_TIME_T1, ZKP_PROG_TIME_T3, ZKP_PROG_TIME_T3E, ZKP_PROG_TIME_T6, ZKP_PROG_TIME_T12, ZKP_PROG_TIME_LIN,
                                ZKP_PROG_TIME_CYC, ZKP_PROG_TIME_CYCSD, ZKP_PROG_TIME_FILL};
-    if (which < 0 || which > 11 || !n || n > 0x7fffffffu || (which >= 10 && n > d->chunk)) return hipErrorInvalidValue;
+    static const int ids2[3] = {ZKP_PROG_TIME_T6S, ZKP_PROG_TIME_T12S, ZKP_PROG_TIME_T12B};   // which 12..14: one-slot / B-two-slot operand forms
+    if (which < 0 || which > 14 || !n || n > 0x7fffffffu || ((which == 10 || which == 11) && n > d->chunk)) return hipErrorInvalidValue;
     hipError_t e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, (size_t)ST_SIZE * n * 64);
     if (e != hipSuccess) return e;
-    if (which >= 10 && (e = ensure_buf(&d->pipe[0].lines, &d->pipe[0].lines_bytes, (size_t)NLINES * 6 * n * 64)) != hipSuccess) return e;
+    if ((which == 10 || which == 11) && (e = ensure_buf(&d->pipe[0].lines, &d->pipe[0].lines_bytes, (size_t)NLINES * 6 * n * 64)) != hipSuccess) return e;
     CoopPipe v = d->pipe[0];
     v.stream = s;
     auto once = [&]() -> hipError_t {
-        if (which == 9) return run_ksq(s, v.state, (uint32_t)n, (uint32_t)n, 0, 12, 400, 1ull << 63);
+        if (which == 9) return run_ksq(s, v.state, (uint32_t)n, (uint32_t)n, 0, 12, 400, 0);   // timing run: no snapshots (a mask needs nsq <= 64)
+        if (which >= 12) return run_prog(d, &v, ids2[which - 12], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
         if (which == 10) {
             const uint64_t* zero = (const uint64_t*)v.state;      // 36 u64 of zeros per pair: the state buffer is far larger
             return prep(&v, zero, zero + 12 * n, nullptr, nullptr, 0, (uint32_t)n, 1, 0, 1);
