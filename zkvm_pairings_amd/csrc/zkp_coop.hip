@@ -862,12 +862,85 @@ __device__ __forceinline__ void add_step(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, c
     l0 = t10; l1 = t1; l2 = t9;
 }
 
+// ---- the same two steps in homogeneous projective coordinates, for the FUSED paths only (zkp_pairing_* / zkp_pairing_check_*):
+// those expose Gt and flags, and any factor of the Miller value that lies in Fp2 dies in the final exponentiation's
+// f^(p^6 - 1), so the lines may be scaled freely and the point may live in whatever coordinates are cheapest.
+// zkp_multi_miller_loop_batch keeps the upstream-shaped value (Alg. 26 / 27 above).
+// Costello-Lange-Naehrig doubling (ePrint 2009/615; Aranha et al. ePrint 2010/526 eq. (10)) on (X : Y : W), W = 2 Z, scaled
+// by 4 so that no halving is left; b' = 4 xi (src/common.rs:69-71: B2 = (4, 4)), so 3 b' Z^2 = 3 xi W^2:
+//   B = Y^2, C = W^2, H2 = (Y + W)^2 - B - C = 2 Y W, E = 3 xi C, F = 3 E,
+//   X' = ((X + Y)^2 - X^2 - B) (B - F) = 2 X Y (B - F),   Y' = (B + F)^2 - 3 (2 E)^2,   W' = 4 B H2
+//   line (times 2 / Z): 2 (B - E)  -  6 X^2 xP  +  H2 yP        [the (c0, c1, c4) operands of mul_by_014]
+// Seven Fp2 squarings and two products: 13 products and 11 reductions per lane against 16 and 13 of Alg. 26.
+template <int L, int A, int B>
+__device__ __forceinline__ Bd<2 * L, (A - B), (A + B) < 2 * B ? 2 * B : (A + B)> bd_xi(const Bd<L, A, B>& a, int c) {
+    // (1 + u) (a0 + a1 u) = (a0 - a1) + (a0 + a1) u : this lane's coefficient, the partner's by DPP
+    Bd<2 * L, (A - B), (A + B) < 2 * B ? 2 * B : (A + B)> r;
+    Fp28 o;
+    swap_pair(o, a.v);
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v.l[i] = c ? o.l[i] + a.v.l[i] : a.v.l[i] - o.l[i];
+    return r;
+}
+template <class S0, class S1, class S2>
+__device__ __forceinline__ void dbl_step_cln(G2C& r, int c, S0&& sink_l0, S1&& sink_l1, S2&& sink_l2) {
+    Bd<1, -33, 68> x, y, w;    // renormalised by the previous step, or a reduced input coordinate / the constant 2 (the first step)
+    x.v = r.x; y.v = r.y; w.v = r.z;
+    auto B = bd_sqr(y, c);
+    auto C = bd_sqr(w, c);
+    auto H2 = bd_sub(bd_sub(bd_sqr(bd_add(y, w), c), B), C);
+    sink_l0(bd_for_fmul(H2));
+    auto xiC = bd_xi(C, c);
+    auto E = bd_vred(bd_add(bd_add(xiC, xiC), xiC));
+    sink_l2(bd_for_vred(bd_dbl(bd_sub(B, E))));
+    auto X2 = bd_sqr(x, c);
+    {
+        auto X6 = bd_dbl(bd_add(bd_add(X2, X2), X2));
+        sink_l1(bd_for_fmul(bd_neg(X6)));
+    }
+    auto XY2 = bd_sub(bd_sub(bd_sqr(bd_add(x, y), c), X2), B);
+    auto F = bd_add(bd_add(E, E), E);
+    auto nx = bd_mul(XY2, bd_sub(B, F), c);
+    auto S = bd_sqr(bd_norm(bd_add(B, F)), c);
+    auto T = bd_sqr(bd_dbl(E), c);
+    auto ny = bd_sub(S, bd_add(bd_add(T, T), T));
+    auto nw = bd_dbl(bd_dbl(bd_mul(B, H2, c)));
+    r.x = nx.v;                 // a reduced product is a valid input as it stands
+    r.y = bd_vred(ny).v;
+    r.z = bd_vred(nw).v;
+}
+// mixed addition T + Q on the same coordinates (Aranha et al. eq. (13), (14) with every quantity doubled: W = 2 Z):
+//   th = 2 Y - y2 W, la = 2 X - x2 W, C = th^2, D = la^2, E = la D, F = W C, G = 2 X D, H = E + F - 2 G,
+//   X' = la H, Y' = th (G - H) - 2 Y E, W' = 2 W E        line (times 2): la yP - th xP + (th x2 - la y2)
+// Five of the 68 steps: written with normalising additions, no bound bookkeeping beyond |v| < 8 p at every product.
+__device__ __forceinline__ void add_step_cln(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, const Fp28& qx, const Fp28& qy, int c) {
+    Fp28 th = c_sub(c_dbl(r.y), c_mul(qy, r.z, c));
+    Fp28 la = c_sub(c_dbl(r.x), c_mul(qx, r.z, c));
+    vred(th.l); vred(la.l);
+    l2 = c_sub(c_mul(th, qx, c), c_mul(la, qy, c));
+    l1 = c_neg(th);
+    l0 = la;
+    Fp28 C = c_sqr(th, c), D = c_sqr(la, c);
+    Fp28 E = c_mul(la, D, c), F = c_mul(r.z, C, c), G = c_mul(c_dbl(r.x), D, c);
+    Fp28 H = c_sub(c_add(E, F), c_dbl(G));
+    vred(H.l);
+    Fp28 GH = c_sub(G, H);
+    vred(GH.l);
+    Fp28 nx = c_mul(la, H, c);
+    Fp28 ny = c_sub(c_mul(th, GH, c), c_mul(c_dbl(r.y), E, c));
+    Fp28 nw = c_dbl(c_mul(r.z, E, c));
+    vred(ny.l); vred(nw.l);
+    r.x = nx; r.y = ny; r.z = nw;
+}
+
 // two lanes per pair: write the 68-step line stream of pair `pid` (check = pid / k, j = pid % k);
 // lane c writes the records of Fp2 coefficient c.  The k pairs are pairs j0 .. j0+k-1 of the check's k_in
 // input pairs (k_in > k when a check is processed in groups of at most eight pairs).
 #ifndef ZKP_PREP_WAVES
 #define ZKP_PREP_WAVES 2   // measured: 256 VGPRs (2 waves/SIMD) 6.6 ms, 168 -> 9.3 ms, 128 -> 11.4 ms per 2^17 pairs (spill traffic)
 #endif
+// CLN: homogeneous projective steps with freely scaled lines (fused pairing paths); otherwise the upstream-shaped Alg. 26 / 27.
+template <bool CLN>
 __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
                                                        uint32_t n_pairs, uint32_t k, uint32_t k_in, uint32_t j0, uint32_t nc, int4* lines) {
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
@@ -912,6 +985,7 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
         park_st(QY, r.y);
     }
     if (c == 0) f_set(r.z, K28_ONE); else f_zero(r.z);
+    if (CLN) r.z = c_dbl(r.z);    // W = 2 Z
     uint32_t step = 0;
     // stream order (c2, c1 * xP, c0 * yP) = the (c0, c1, c4) operands of mul_by_014; a pair with an infinity streams
     // the neutral line (1, 0, 0)
@@ -930,11 +1004,11 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
     const uint64_t xs = 0xd201000000010000ULL;
 #pragma unroll 1
     for (int b = 62; b >= 0; b--) {
-        dbl_step(r, c, sink_l0, sink_l1, sink_l2);
+        if (CLN) dbl_step_cln(r, c, sink_l0, sink_l1, sink_l2); else dbl_step(r, c, sink_l0, sink_l1, sink_l2);
         step++;
         if ((xs >> b) & 1) {
             Fp28 l0, l1, l2;
-            add_step(l0, l1, l2, r, park_ld(QX), park_ld(QY), c);
+            if (CLN) add_step_cln(l0, l1, l2, r, park_ld(QX), park_ld(QY), c); else add_step(l0, l1, l2, r, park_ld(QX), park_ld(QY), c);
             sink_l2(l2);
             sink_l1(l1);
             sink_l0(l0);
@@ -1669,13 +1743,19 @@ constexpr size_t MAX_GROUP = 8;   // pairs per Miller program (shared squarings)
 bool coop_supports_k(size_t k) { return k >= 1 && k <= 0xffffu; }
 
 // line stream of pairs j0 .. j0+g-1 of each of the n checks starting at base_check (k_in pairs per check)
+// fused: the Miller value only feeds a final exponentiation inside the same call (homogeneous projective steps, freely scaled lines)
 static hipError_t prep(CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t base_check, uint32_t n,
-                       uint32_t k_in, uint32_t j0, uint32_t g) {
+                       uint32_t k_in, uint32_t j0, uint32_t g, bool fused) {
     hipStream_t s = pp->stream;
     size_t p0 = base_check * k_in;
     uint32_t n_pairs = n * g;
-    hipLaunchKernelGGL(k_prep_lines, dim3((2 * n_pairs + 63) / 64), dim3(64), 0, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
-                       i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines);
+    static const char* no_cln = getenv("ZKP_PREP_NO_CLN");   // A/B knob
+    if (fused && !(no_cln && atoi(no_cln)))
+        hipLaunchKernelGGL(k_prep_lines<true>, dim3((2 * n_pairs + 63) / 64), dim3(64), 0, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
+                           i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines);
+    else
+        hipLaunchKernelGGL(k_prep_lines<false>, dim3((2 * n_pairs + 63) / 64), dim3(64), 0, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
+                           i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines);
     return hipGetLastError();
 }
 
@@ -1684,15 +1764,15 @@ static hipError_t prep(CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, con
 // (prod_i f_i is the multi-Miller value; only the shared squarings are lost).  Result: state ST_F, or the
 // canonical wire record in `wire_out` when that is not null.
 static hipError_t miller_on_pipe(CoopDev* d, CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2,
-                                 size_t base, uint32_t n, uint32_t nc, size_t k, uint64_t* wire_out) {
+                                 size_t base, uint32_t n, uint32_t nc, size_t k, uint64_t* wire_out, bool fused = false) {
     hipError_t e;
     if (k <= MAX_GROUP) {
-        if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, 0, (uint32_t)k)) != hipSuccess) return e;
+        if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, 0, (uint32_t)k, fused)) != hipSuccess) return e;
         return run_prog(d, pp, miller_prog(k, wire_out != nullptr), n, nc, (uint32_t)k, nullptr, wire_out, nullptr, nullptr);
     }
     for (size_t j0 = 0; j0 < k; j0 += MAX_GROUP) {
         const size_t g = k - j0 < MAX_GROUP ? k - j0 : MAX_GROUP;
-        if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, (uint32_t)j0, (uint32_t)g)) != hipSuccess) return e;
+        if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, (uint32_t)j0, (uint32_t)g, fused)) != hipSuccess) return e;
         if ((e = run_prog(d, pp, miller_prog(g, false), n, nc, (uint32_t)g, nullptr, nullptr, nullptr, nullptr, j0 ? ZKP_COOP_ST_G : 0)) != hipSuccess)
             return e;
         if (j0) {
@@ -1864,7 +1944,7 @@ hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, c
     CoopDev* d = (CoopDev*)st->d_prog;
     if (!coop_supports_k(k)) return hipErrorNotSupported;
     return two_phase(d, n_checks, k, true, s, out_gt, ok, all_ok, [&](CoopPipe* pp, size_t base, uint32_t n, uint32_t nc) -> hipError_t {
-        hipError_t e = miller_on_pipe(d, pp, g1, g2, i1, i2, base, n, nc, k, nullptr);
+        hipError_t e = miller_on_pipe(d, pp, g1, g2, i1, i2, base, n, nc, k, nullptr, true);
         if (e != hipSuccess) return e;
         return run_prog(d, pp, ZKP_PROG_FEXP_A_STATE, n, nc, 1, nullptr, nullptr, nullptr, nullptr);
     });
@@ -1927,7 +2007,7 @@ hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, hip
         if (which >= 12) return run_prog(d, &v, ids2[which - 12], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
         if (which == 10) {
             const uint64_t* zero = (const uint64_t*)v.state;      // 36 u64 of zeros per pair: the state buffer is far larger
-            return prep(&v, zero, zero + 12 * n, nullptr, nullptr, 0, (uint32_t)n, 1, 0, 1);
+            return prep(&v, zero, zero + 12 * n, nullptr, nullptr, 0, (uint32_t)n, 1, 0, 1, true);
         }
         if (which == 11) return run_prog(d, &v, ZKP_PROG_MILLER1_STATE, (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
         return run_prog(d, &v, ids[which], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
