@@ -213,6 +213,22 @@ int zkp_pairing_check_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_
 int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1,
                             const uint8_t* inf2, size_t n, uint64_t* out_gt, uint8_t* ok, int* all_ok);
 
+/* ---- pinned host memory for the host-pointer entry points ("H2D/D2H per GPU straight from pinned host
+ * memory on its own stream") ------------------------------------------------------------------------------------------
+ * The host-pointer entry points copy with hipMemcpyAsync on their own streams.  From PAGEABLE memory such a copy stages
+ * through a driver buffer and blocks the calling thread, so the next slice's upload (zkp_pairing_batch) or the next
+ * context's upload (zkp_pairing_*_multi) cannot start before it is over; from page-locked memory it is a DMA that
+ * overlaps the kernels and the other contexts' copies.  zkp_host_alloc returns page-locked memory usable with every
+ * context / GPU of the process (hipHostMallocPortable); zkp_host_register page-locks an existing allocation in place
+ * (hipHostRegister: slow, of the order of 1 ms per 4 MB - do it once for a buffer that is reused, not per call).  The
+ * entry points themselves accept either kind of memory and give the same results.  No reference counterpart: the
+ * reference is a host-only crate (its point arrays would live in a Vec; the Rust wrapper's PinnedVec in
+ * integration/rust/src/lib.rs is the drop-in container). */
+int zkp_host_alloc(size_t bytes, void** out_ptr);
+int zkp_host_free(void* ptr);
+int zkp_host_register(void* ptr, size_t bytes);
+int zkp_host_unregister(void* ptr);
+
 /* ---- measurement helper used by bench.py: times `reps` launches of the fused pairing kernel on
  * ctx's own stream with HIP events recorded on THAT stream; returns average ms per launch. ---- */
 int zkp_time_pairing_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out_gt, int reps,

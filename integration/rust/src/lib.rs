@@ -71,6 +71,12 @@ extern "C" {
     pub fn zkp_pairing_batch_multi(ctxs: *const *mut ZkpCtx, n_ctx: c_int, g1: *const u64, g2: *const u64, inf1: *const u8,
                                    inf2: *const u8, n: usize, out_gt: *mut u64, ok: *mut u8, all_ok: *mut c_int) -> c_int;
 
+    // page-locked host memory: from it the host-pointer entry points' copies are DMAs that overlap the kernels
+    pub fn zkp_host_alloc(bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
+    pub fn zkp_host_free(ptr: *mut c_void) -> c_int;
+    pub fn zkp_host_register(ptr: *mut c_void, bytes: usize) -> c_int;
+    pub fn zkp_host_unregister(ptr: *mut c_void) -> c_int;
+
     // device-pointer flavours (buffers resident in HBM, asynchronous on a hipStream_t passed as *mut c_void)
     pub fn zkp_pairing_batch_dev(ctx: *mut ZkpCtx, d_g1: *const c_void, d_g2: *const c_void, d_inf1: *const c_void,
                                  d_inf2: *const c_void, n: usize, d_out_gt: *mut c_void, stream: *mut c_void) -> c_int;

@@ -118,6 +118,15 @@ def test_tower_ops_direct_vs_oracle(keng, ref_kats):
     check("fp6_mul", a6, b6, 36, lambda i: o.fp6_mul(a6[i, :36], b6[i, :36]))
     check("fp6_square", a6, None, 36, lambda i: o.fp6_square(a6[i, :36]))
     check("fp6_frobenius", a6, None, 36, lambda i: o.fp6_frobenius_map(a6[i, :36]))
+    # the header asks for a zero tail; an input that carries garbage behind its 36 words must still give the Fp6 result with
+    # a zero tail on BOTH kernel families (the cooperative one runs its Fp12 program and clears the upper half)
+    dirty = a6.copy()
+    dirty[:, 36:] = _rnd_records(37, n, 6)[:, :36]
+    got = keng.tower_op("fp6_frobenius", dirty, None)
+    for i in range(n):
+        want = np.zeros(72, dtype=np.uint64)
+        want[:36] = o.fp6_frobenius_map(a6[i, :36])
+        assert np.array_equal(got[i], want), ("fp6_frobenius with a garbage tail", i)
     check("fp12_mul", a12, b12, 72, lambda i: o.fp12_mul(a12[i], b12[i]))
     check("fp12_square", a12, None, 72, lambda i: o.fp12_square(a12[i]))
     check("fp12_mul_by_014", a12, b6, 72, lambda i: o.fp12_mul_by_014(a12[i], b6[i, :12], b6[i, 12:24], b6[i, 24:36]))

@@ -3,6 +3,7 @@
 Loading this package loads libzkp_pairings.so (the C ABI in include/zkp_pairings.h); it raises if
 the library has not been built.  There is no CPU fallback."""
 from . import _lib
+from ._lib import ZkpError
 
 _lib.load()
 
@@ -12,4 +13,4 @@ from .pairings import (G1Affine, G2Affine, Gt, MillerLoopResult, final_exponenti
 from . import synthetic  # noqa: E402
 
 __all__ = ["PairingEngine", "G1Affine", "G2Affine", "Gt", "MillerLoopResult", "pairing", "multi_miller_loop",
-           "final_exponentiation", "synthetic", "KERNEL_AUTO", "KERNEL_THREAD", "KERNEL_COOP"]
+           "final_exponentiation", "synthetic", "ZkpError", "KERNEL_AUTO", "KERNEL_THREAD", "KERNEL_COOP"]

@@ -58,6 +58,10 @@ SIGNATURES = {
     "zkp_take_validation_status_dev": (c_int, [c_vp, c_vp, ctypes.POINTER(c_int)]),
     "zkp_pairing_check_batch_multi": (c_int, [ctypes.POINTER(c_vp), c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, ctypes.POINTER(c_int)]),
     "zkp_pairing_batch_multi": (c_int, [ctypes.POINTER(c_vp), c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.POINTER(c_int)]),
+    "zkp_host_alloc": (c_int, [c_sz, ctypes.POINTER(c_vp)]),
+    "zkp_host_free": (c_int, [c_vp]),
+    "zkp_host_register": (c_int, [c_vp, c_sz]),
+    "zkp_host_unregister": (c_int, [c_vp]),
     "zkp_clock_probe_dev": (c_int, [c_vp, c_vp, ctypes.c_uint, c_vp, ctypes.POINTER(c_int)]),
     "zkp_time_coop_step": (c_int, [c_vp, c_int, c_sz, ctypes.POINTER(ctypes.c_float)]),
     "zkp_time_pairing_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_int, ctypes.POINTER(ctypes.c_float)]),

@@ -1966,6 +1966,9 @@ hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, ui
         v.stream = s;
         if (op <= 10) {
             if ((e = run_prog(d, &v, progs[op], m, m, 1, ab + 72 * base, out + 72 * base, nullptr, nullptr, 0, (uint32_t)n)) != hipSuccess) return e;
+            // ZKP_TOWER_FP6_FROBENIUS runs the Fp12 program; the Fp6 result is its c0 half, the rest of the record is zero whatever
+            // the input's tail held (as the thread family's k_tower_op writes it)
+            if (op == 4 && (e = hipMemset2DAsync(out + 72 * base + 36, 576, 0, 288, m, s)) != hipSuccess) return e;
             continue;
         }
         if (op == 11 && (repeat < 1 || repeat > 64)) return hipErrorInvalidValue;

@@ -62,20 +62,23 @@ __device__ __forceinline__ void acc_mul_k(Acc& acc, AccMid& mid, const int32_t* 
     int32_t da[NH], db[NH];
 #pragma unroll
     for (int i = 0; i < NH; i++) { da[i] = a[i + NH] - a[i]; db[i] = b[i] - b[i + NH]; }
+    // the middle columns (and only they) may pass 2^63 on the way - the sums are taken in uint64_t, where wrap-around is defined
+    auto wadd = [](int64_t x, int64_t y) -> int64_t { return (int64_t)((uint64_t)x + (uint64_t)y); };
 #pragma unroll
     for (int i = 0; i < NH; i++)
 #pragma unroll
         for (int j = 0; j < NH; j++) {
             acc.c[i + j] += (int64_t)a[i] * (int64_t)b[j];
             acc.c[NL + i + j] += (int64_t)a[NH + i] * (int64_t)b[NH + j];
-            mid.c[i + j] += (int64_t)da[i] * (int64_t)db[j];
+            mid.c[i + j] = wadd(mid.c[i + j], (int64_t)da[i] * (int64_t)db[j]);
         }
 }
 __device__ __forceinline__ void acc_fold(Acc& acc, AccMid& mid) {
+    auto wadd = [](int64_t x, int64_t y) -> int64_t { return (int64_t)((uint64_t)x + (uint64_t)y); };
 #pragma unroll
-    for (int k = 0; k < 2 * NH - 1; k++) mid.c[k] += acc.c[k] + acc.c[NL + k];
+    for (int k = 0; k < 2 * NH - 1; k++) mid.c[k] = wadd(mid.c[k], wadd(acc.c[k], acc.c[NL + k]));
 #pragma unroll
-    for (int k = 0; k < 2 * NH - 1; k++) acc.c[NH + k] += mid.c[k];
+    for (int k = 0; k < 2 * NH - 1; k++) acc.c[NH + k] = wadd(acc.c[NH + k], mid.c[k]);
 }
 
 // sign-extended low 28 bits: value in [-2^27, 2^27)

@@ -1199,6 +1199,18 @@ static int multi_impl(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1, const
     int flags[64];
     int rc = ZKP_OK, used = 0;
     const size_t base = n_checks / n_ctx, rem = n_checks % n_ctx;
+    // workspace of every context first: an allocation synchronises its device, and must not do so between another context's
+    // upload and launch.  After this pass the loop below only queues work: from page-locked arrays (zkp_host_alloc /
+    // zkp_host_register) no context's start waits for another context's copy.
+    for (int j = 0; j < n_ctx; j++) {
+        zkp_ctx* c = ctxs[j];
+        const size_t m = base + ((size_t)j < rem ? 1 : 0);
+        if (!m) continue;
+        if ((rc = bind(c))) return rc;
+        if ((rc = ensure(c, 0, m * k * 96)) || (rc = ensure(c, 1, m * k * 192)) || (inf1 && (rc = ensure(c, 2, m * k))) ||
+            (inf2 && (rc = ensure(c, 3, m * k))) || (out_gt && (rc = ensure(c, 4, m * 576))) || (rc = ensure(c, 6, m)))
+            return rc;
+    }
     for (int j = 0; j < n_ctx && rc == ZKP_OK; j++) {
         zkp_ctx* c = ctxs[j];
         const size_t lo = j * base + ((size_t)j < rem ? j : rem), m = base + ((size_t)j < rem ? 1 : 0), p0 = lo * k;
@@ -1242,6 +1254,19 @@ int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1,
     return multi_impl(ctxs, n_ctx, g1, g2, inf1, inf2, n, 1, out_gt, ok, all_ok);
 }
 
+// page-locked host memory for the host-pointer entry points (header: "pinned host memory")
+int zkp_host_alloc(size_t bytes, void** out_ptr) {
+    if (!out_ptr || !bytes) return ZKP_ERR_ARG;
+    *out_ptr = nullptr;
+    return hipHostMalloc(out_ptr, bytes, hipHostMallocPortable) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP;
+}
+int zkp_host_free(void* ptr) { return !ptr || hipHostFree(ptr) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP; }
+int zkp_host_register(void* ptr, size_t bytes) {
+    if (!ptr || !bytes) return ZKP_ERR_ARG;
+    return hipHostRegister(ptr, bytes, hipHostRegisterPortable) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP;
+}
+int zkp_host_unregister(void* ptr) { return ptr && hipHostUnregister(ptr) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP; }
+
 // measurement helper: a one-wavefront clock probe on `stream` (asynchronous); d_out receives two u64: shader clock ticks
 // and wall clock ticks over about spin_us microseconds; *wall_khz (host) is the wall clock's rate.
 int zkp_clock_probe_dev(zkp_ctx* c, void* stream, unsigned spin_us, void* d_out, int* wall_khz) {
@@ -1261,6 +1286,7 @@ int zkp_time_coop_step(zkp_ctx* c, int which, size_t n, float* ms) {
     if (!c || !ms) return ZKP_ERR_ARG;
     int rc = bind(c);
     if (rc) return rc;
+    HostCall hc(c);   // the timing programs reuse the workspace of pipeline 0: wait for *_dev calls queued on other streams, drain on exit
     HIPCHK(c, zkp::coop_time_prog(&c->coop, which, n, c->stream, c->ev0, c->ev1, ms));
     return ZKP_OK;
 }
@@ -1269,6 +1295,7 @@ int zkp_time_pairing_dev(zkp_ctx* c, const void* g1, const void* g2, size_t n, v
     if (!c || !g1 || !g2 || !out || reps <= 0 || !avg_ms) return ZKP_ERR_ARG;
     int rc = bind(c);
     if (rc) return rc;
+    HostCall hc(c);   // same workspace discipline as every host-synchronous entry point
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     for (int r = 0; r < reps; r++)
         if ((rc = pairing_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, nullptr, nullptr, n, 1, (uint64_t*)out, nullptr, nullptr, c->stream))) return rc;

@@ -55,6 +55,17 @@ def max_over_ranks(seconds, device):
     return float(t.item())
 
 
+def gather_rows(row, device):
+    """row: 1-D float64 host tensor of this rank -> (world, len) list of lists on every rank (diagnostics of bench.py: one
+    all_gather of a few numbers, outside any timed region)"""
+    if not _active():
+        return [row.tolist()]
+    src = row.contiguous() if _host_backend() else row.to(device)
+    parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, src)
+    return [p.cpu().tolist() for p in parts]
+
+
 def sharded_pairing_check(check_fn, n_checks, device):
     """check_fn(lo, hi) -> int32 tensor (1,) with the AND over this rank's checks [lo, hi).
     Returns the global AND as a python bool on every rank."""

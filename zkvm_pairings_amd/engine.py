@@ -94,8 +94,25 @@ class PairingEngine:
         return np.array([p[i] for i in range(72)], dtype=np.uint64)
 
     # ------------------------------------------------------------------ host-array API
-    def pairing(self, g1, g2, inf1=None, inf2=None):
-        """out[i] = pairing(g1[i], g2[i])  -> (n,72) canonical Gt"""
+    @staticmethod
+    def host_array(shape, dtype=np.uint64):
+        """numpy array in page-locked host memory (zkp_host_alloc): the host-pointer entry points copy from / into such an
+        array by DMA, overlapped with the kernels; a pageable array works too, its copies block the calling thread.  The
+        memory is released when the array (and every view of it) is gone."""
+        import weakref
+        lib = _lib.load()
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        st = lib.zkp_host_alloc(max(nbytes, 1), ctypes.byref(p))
+        if st != 0:
+            raise _lib.ZkpError(st, "zkp_host_alloc(%d bytes)" % nbytes)
+        buf = (ctypes.c_ubyte * max(nbytes, 1)).from_address(p.value)
+        weakref.finalize(buf, lib.zkp_host_free, ctypes.c_void_p(p.value))
+        return np.frombuffer(buf, dtype=dtype, count=nbytes // np.dtype(dtype).itemsize).reshape(shape)
+
+    def pairing(self, g1, g2, inf1=None, inf2=None, out=None):
+        """out[i] = pairing(g1[i], g2[i])  -> (n,72) canonical Gt (into `out` when given, e.g. a host_array)"""
         if _is_torch(g1):
             return self._pairing_t(g1, g2, inf1, inf2)
         g1, g2 = _np(g1, 12), _np(g2, 24)
@@ -103,7 +120,10 @@ class PairingEngine:
         if g2.shape[0] != n:
             raise ValueError("g1 and g2 hold different numbers of points")
         i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
-        out = np.empty((n, 72), dtype=np.uint64)
+        if out is None:
+            out = np.empty((n, 72), dtype=np.uint64)
+        elif not (isinstance(out, np.ndarray) and out.dtype == np.uint64 and out.shape == (n, 72) and out.flags["C_CONTIGUOUS"]):
+            raise ValueError("out must be a C-contiguous (n, 72) uint64 array")
         self._chk(self._lib.zkp_pairing_batch(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n, _ptr(out)))
         return out
 
