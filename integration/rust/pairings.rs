@@ -42,6 +42,16 @@
 //! ```
 //!
 //! and to Cargo.toml: `zkp-pairings-sys = { path = "<this repository>/integration/rust" }`.
+//!
+//! Two API layers:
+//!   * the crate-shaped, context-free functions the north star names - `pairing(&G1Affine, &G2Affine) -> Gt`,
+//!     `multi_miller_loop(&[(&G1Affine, &G2Affine)]) -> MillerLoopResult`, `final_exponentiation(&MillerLoopResult) -> Gt`,
+//!     `Gt::identity()` - exactly the signatures an upstream `pairings.rs` would export next to src/lib.rs:12.  They run on a
+//!     process-global engine that is created on first use (device `ZKP_DEVICE`, default 0) and serialised by a mutex.  A
+//!     function of this shape has no error channel: a GPU failure there PANICS with the library's message, the same way the
+//!     crate's own arithmetic panics on its `unwrap`s;
+//!   * the batched functions on an explicit `Gpu` - what a verifier should call, one launch for thousands of pairings - which
+//!     return `Result<_, sys::Error>` and never panic on a GPU error.
 use core::marker::PhantomData;
 
 use zkp_pairings_sys as sys;
@@ -105,8 +115,9 @@ impl<C: Curve> PartialEq for Gt<C> {
 pub struct MillerLoopResult<C: Curve>(pub Fp12<C>);
 
 impl<C: Curve> MillerLoopResult<C> {
-    pub fn final_exponentiation(&self, gpu: &mut Gpu<C>) -> Gt<C> {
-        final_exponentiation(gpu, self)
+    /// f^(3 (p^12 - 1) / r) on the process-global engine (panics on a GPU error; `Gpu::final_exponentiation_batch` does not)
+    pub fn final_exponentiation(&self) -> Gt<C> {
+        final_exponentiation(self)
     }
 }
 
@@ -114,13 +125,6 @@ impl<C: Curve> MillerLoopResult<C> {
 pub struct Gpu<C: Curve> {
     eng: sys::Engine,
     _c: PhantomData<C>,
-}
-
-impl<C: Curve> Gpu<C> {
-    /// device = HIP device ordinal of this process
-    pub fn new(device: i32) -> Result<Self, sys::Error> {
-        Ok(Gpu { eng: sys::Engine::new(device)?, _c: PhantomData })
-    }
 }
 
 fn pack<C: Curve>(terms: &[(&G1Affine<C>, &G2Affine<C>)]) -> (Vec<u64>, Vec<u64>, Vec<u8>, Vec<u8>) {
@@ -138,73 +142,119 @@ fn pack<C: Curve>(terms: &[(&G1Affine<C>, &G2Affine<C>)]) -> (Vec<u64>, Vec<u64>
     (g1, g2, i1, i2)
 }
 
-/// e(P, Q).  A pair with a point at infinity gives `Gt::identity()`.
-pub fn pairing<C: Curve>(gpu: &mut Gpu<C>, p: &G1Affine<C>, q: &G2Affine<C>) -> Gt<C> {
-    let (g1, g2, i1, i2) = pack(&[(p, q)]);
-    let out = gpu.eng.pairing_batch(&g1, &g2, Some(&i1), Some(&i2)).expect("zkp_pairing_batch");
-    Gt(fp12_from_raw(&out))
-}
-
-/// prod_i f_{|x|, Q_i}(P_i), conjugated: ONE Miller loop with shared squarings over all terms.
-pub fn multi_miller_loop<C: Curve>(gpu: &mut Gpu<C>, terms: &[(&G1Affine<C>, &G2Affine<C>)]) -> MillerLoopResult<C> {
-    if terms.is_empty() {
-        return MillerLoopResult(Fp12::one());
-    }
-    let (g1, g2, i1, i2) = pack(terms);
-    let out = gpu.eng.multi_miller_loop_batch(&g1, &g2, Some(&i1), Some(&i2), terms.len()).expect("zkp_multi_miller_loop_batch");
-    MillerLoopResult(fp12_from_raw(&out))
-}
-
-/// f^(3 (p^12 - 1) / r)
-pub fn final_exponentiation<C: Curve>(gpu: &mut Gpu<C>, f: &MillerLoopResult<C>) -> Gt<C> {
-    let out = gpu.eng.final_exponentiation_batch(&fp12_to_raw(&f.0)).expect("zkp_final_exponentiation_batch");
-    Gt(fp12_from_raw(&out))
-}
-
-/// The batched form a verifier wants (this is where a GPU pays off): `checks.len() / k` checks of k terms each,
-/// check c = terms [c k, (c + 1) k); returns (flag per check: product of its pairings == Gt::identity(), AND of all flags).
-pub fn pairing_check_batch<C: Curve>(gpu: &mut Gpu<C>, terms: &[(&G1Affine<C>, &G2Affine<C>)], k: usize) -> (Vec<bool>, bool) {
-    assert!(k > 0 && terms.len() % k == 0);
-    let (g1, g2, i1, i2) = pack(terms);
-    let (ok, all) = gpu.eng.pairing_check_batch(&g1, &g2, Some(&i1), Some(&i2), k).expect("zkp_pairing_check_batch");
-    (ok.into_iter().map(|b| b != 0).collect(), all)
-}
-
-/// pairing() of many pairs in one call
-pub fn pairing_batch<C: Curve>(gpu: &mut Gpu<C>, pairs: &[(&G1Affine<C>, &G2Affine<C>)]) -> Vec<Gt<C>> {
-    let (g1, g2, i1, i2) = pack(pairs);
-    let out = gpu.eng.pairing_batch(&g1, &g2, Some(&i1), Some(&i2)).expect("zkp_pairing_batch");
-    out.chunks_exact(72).map(|c| Gt(fp12_from_raw(c))).collect()
-}
-
-/// `G1Affine::is_valid` / `G2Affine::is_valid` (src/g1.rs:49-62, src/g2.rs:57-69) for many points: the crate's
-/// `Result<(), String>` with the crate's own messages
-pub fn g1_is_valid_batch<C: Curve>(gpu: &mut Gpu<C>, pts: &[&G1Affine<C>]) -> Vec<Result<(), String>> {
-    let mut limbs = Vec::with_capacity(12 * pts.len());
-    let mut inf = Vec::with_capacity(pts.len());
-    for p in pts {
-        let (a, i) = p.to_raw();
-        limbs.extend_from_slice(&a);
-        inf.push(i);
-    }
-    gpu.eng.g1_is_valid_batch(&limbs, Some(&inf)).expect("zkp_g1_is_valid_batch").into_iter().map(status_to_result).collect()
-}
-
-pub fn g2_is_valid_batch<C: Curve>(gpu: &mut Gpu<C>, pts: &[&G2Affine<C>]) -> Vec<Result<(), String>> {
-    let mut limbs = Vec::with_capacity(24 * pts.len());
-    let mut inf = Vec::with_capacity(pts.len());
-    for p in pts {
-        let (a, i) = p.to_raw();
-        limbs.extend_from_slice(&a);
-        inf.push(i);
-    }
-    gpu.eng.g2_is_valid_batch(&limbs, Some(&inf)).expect("zkp_g2_is_valid_batch").into_iter().map(status_to_result).collect()
-}
-
 fn status_to_result(s: u8) -> Result<(), String> {
     match s {
         0 => Ok(()),
         1 => Err("Point is not on curve".to_string()),          // src/g1.rs:55
         _ => Err("Point is not torsion free".to_string()),      // src/g1.rs:58
     }
+}
+
+// ---------------------------------------------------------------------------------------------- batched API: Result, no panics
+impl<C: Curve> Gpu<C> {
+    /// device = HIP device ordinal of this process
+    pub fn new(device: i32) -> Result<Self, sys::Error> {
+        Ok(Gpu { eng: sys::Engine::new(device)?, _c: PhantomData })
+    }
+
+    /// pairing() of many pairs in one call
+    pub fn pairing_batch(&mut self, pairs: &[(&G1Affine<C>, &G2Affine<C>)]) -> Result<Vec<Gt<C>>, sys::Error> {
+        let (g1, g2, i1, i2) = pack(pairs);
+        let out = self.eng.pairing_batch(&g1, &g2, Some(&i1), Some(&i2))?;
+        Ok(out.chunks_exact(72).map(|c| Gt(fp12_from_raw(c))).collect())
+    }
+
+    /// `terms.len() / k` Miller loops of k terms each (shared squarings within a group)
+    pub fn multi_miller_loop_batch(&mut self, terms: &[(&G1Affine<C>, &G2Affine<C>)], k: usize) -> Result<Vec<MillerLoopResult<C>>, sys::Error> {
+        if terms.is_empty() {
+            return Ok(Vec::new());
+        }
+        let (g1, g2, i1, i2) = pack(terms);
+        let out = self.eng.multi_miller_loop_batch(&g1, &g2, Some(&i1), Some(&i2), k)?;
+        Ok(out.chunks_exact(72).map(|c| MillerLoopResult(fp12_from_raw(c))).collect())
+    }
+
+    pub fn final_exponentiation_batch(&mut self, fs: &[MillerLoopResult<C>]) -> Result<Vec<Gt<C>>, sys::Error> {
+        let mut raw = Vec::with_capacity(72 * fs.len());
+        for f in fs {
+            raw.extend_from_slice(&fp12_to_raw(&f.0));
+        }
+        let out = self.eng.final_exponentiation_batch(&raw)?;
+        Ok(out.chunks_exact(72).map(|c| Gt(fp12_from_raw(c))).collect())
+    }
+
+    /// The batched form a verifier wants (this is where a GPU pays off): `terms.len() / k` checks of k terms each, check c =
+    /// terms [c k, (c + 1) k); returns (flag per check: product of its pairings == Gt::identity(), AND of all flags).
+    pub fn pairing_check_batch(&mut self, terms: &[(&G1Affine<C>, &G2Affine<C>)], k: usize) -> Result<(Vec<bool>, bool), sys::Error> {
+        let (g1, g2, i1, i2) = pack(terms);
+        let (ok, all) = self.eng.pairing_check_batch(&g1, &g2, Some(&i1), Some(&i2), k)?;
+        Ok((ok.into_iter().map(|b| b != 0).collect(), all))
+    }
+
+    /// `G1Affine::is_valid` / `G2Affine::is_valid` (src/g1.rs:49-62, src/g2.rs:57-69) for many points: per point the crate's
+    /// `Result<(), String>` with the crate's own messages; the outer `Result` is the GPU call's
+    pub fn g1_is_valid_batch(&mut self, pts: &[&G1Affine<C>]) -> Result<Vec<Result<(), String>>, sys::Error> {
+        let mut limbs = Vec::with_capacity(12 * pts.len());
+        let mut inf = Vec::with_capacity(pts.len());
+        for p in pts {
+            let (a, i) = p.to_raw();
+            limbs.extend_from_slice(&a);
+            inf.push(i);
+        }
+        Ok(self.eng.g1_is_valid_batch(&limbs, Some(&inf))?.into_iter().map(status_to_result).collect())
+    }
+
+    pub fn g2_is_valid_batch(&mut self, pts: &[&G2Affine<C>]) -> Result<Vec<Result<(), String>>, sys::Error> {
+        let mut limbs = Vec::with_capacity(24 * pts.len());
+        let mut inf = Vec::with_capacity(pts.len());
+        for p in pts {
+            let (a, i) = p.to_raw();
+            limbs.extend_from_slice(&a);
+            inf.push(i);
+        }
+        Ok(self.eng.g2_is_valid_batch(&limbs, Some(&inf))?.into_iter().map(status_to_result).collect())
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- the crate-shaped, context-free API
+// One engine per process, created on first use.  The curve parameter is a compile-time tag only (the engine is BLS12-381,
+// like the crate's single `Curve` instance, src/common.rs:62-63), so the global holds the untyped sys::Engine.
+static GLOBAL: std::sync::OnceLock<std::sync::Mutex<sys::Engine>> = std::sync::OnceLock::new();
+
+fn with_global<T>(f: impl FnOnce(&mut sys::Engine) -> Result<T, sys::Error>) -> T {
+    let m = GLOBAL.get_or_init(|| {
+        let dev = std::env::var("ZKP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+        std::sync::Mutex::new(sys::Engine::new(dev).unwrap_or_else(|e| panic!("zkvm-pairings: no usable MI355X engine: {e:?}")))
+    });
+    let mut g = m.lock().unwrap_or_else(|p| p.into_inner());
+    f(&mut g).unwrap_or_else(|e| panic!("zkvm-pairings GPU call failed: {e:?}"))
+}
+
+/// e(P, Q).  A pair with a point at infinity gives `Gt::identity()`.
+pub fn pairing<C: Curve>(p: &G1Affine<C>, q: &G2Affine<C>) -> Gt<C> {
+    let (g1, g2, i1, i2) = pack(&[(p, q)]);
+    Gt(fp12_from_raw(&with_global(|e| e.pairing_batch(&g1, &g2, Some(&i1), Some(&i2)))))
+}
+
+/// prod_i f_{|x|, Q_i}(P_i), conjugated: ONE Miller loop with shared squarings over all terms.
+pub fn multi_miller_loop<C: Curve>(terms: &[(&G1Affine<C>, &G2Affine<C>)]) -> MillerLoopResult<C> {
+    if terms.is_empty() {
+        return MillerLoopResult(Fp12::one());
+    }
+    let (g1, g2, i1, i2) = pack(terms);
+    MillerLoopResult(fp12_from_raw(&with_global(|e| e.multi_miller_loop_batch(&g1, &g2, Some(&i1), Some(&i2), terms.len()))))
+}
+
+/// f^(3 (p^12 - 1) / r)
+pub fn final_exponentiation<C: Curve>(f: &MillerLoopResult<C>) -> Gt<C> {
+    Gt(fp12_from_raw(&with_global(|e| e.final_exponentiation_batch(&fp12_to_raw(&f.0)))))
+}
+
+/// The pairing-check shape of the zkVM path: prod_i e(P_i, Q_i) == Gt::identity(), one Miller loop + one final exponentiation
+pub fn pairing_check<C: Curve>(terms: &[(&G1Affine<C>, &G2Affine<C>)]) -> bool {
+    if terms.is_empty() {
+        return true;
+    }
+    let (g1, g2, i1, i2) = pack(terms);
+    with_global(|e| e.pairing_check_batch(&g1, &g2, Some(&i1), Some(&i2), terms.len())).1
 }

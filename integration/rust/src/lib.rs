@@ -115,6 +115,49 @@ pub struct Error {
     pub detail: String,
 }
 
+/// Page-locked host memory (`zkp_host_alloc`): the container to keep point / Gt arrays in when they are handed to the
+/// host-pointer entry points - their copies are then DMAs that overlap the kernels (and, in the multi-GPU call, the other
+/// GPUs' copies) instead of blocking staged copies.  Derefs to a slice; usable with every engine of the process.
+pub struct PinnedVec<T: Copy> {
+    ptr: *mut T,
+    len: usize,
+}
+unsafe impl<T: Copy + Send> Send for PinnedVec<T> {}
+
+impl<T: Copy> PinnedVec<T> {
+    pub fn zeroed(len: usize) -> Result<Self, Error> {
+        let mut p: *mut c_void = core::ptr::null_mut();
+        let bytes = core::cmp::max(1, len * core::mem::size_of::<T>());
+        let rc = unsafe { zkp_host_alloc(bytes, &mut p) };
+        if rc != ZKP_OK {
+            return Err(Error { status: rc, detail: format!("zkp_host_alloc({bytes} bytes)") });
+        }
+        unsafe { core::ptr::write_bytes(p as *mut u8, 0, bytes) };
+        Ok(PinnedVec { ptr: p as *mut T, len })
+    }
+    pub fn from_slice(s: &[T]) -> Result<Self, Error> {
+        let mut v = Self::zeroed(s.len())?;
+        v.copy_from_slice(s);
+        Ok(v)
+    }
+}
+impl<T: Copy> core::ops::Deref for PinnedVec<T> {
+    type Target = [T];
+    fn deref(&self) -> &[T] {
+        unsafe { core::slice::from_raw_parts(self.ptr, self.len) }
+    }
+}
+impl<T: Copy> core::ops::DerefMut for PinnedVec<T> {
+    fn deref_mut(&mut self) -> &mut [T] {
+        unsafe { core::slice::from_raw_parts_mut(self.ptr, self.len) }
+    }
+}
+impl<T: Copy> Drop for PinnedVec<T> {
+    fn drop(&mut self) {
+        unsafe { zkp_host_free(self.ptr as *mut c_void) };
+    }
+}
+
 /// One GPU = one engine.  `Send` but not `Sync`: a `zkp_ctx` is not thread-safe.
 pub struct Engine(*mut ZkpCtx);
 unsafe impl Send for Engine {}
@@ -162,6 +205,16 @@ impl Engine {
         let mut out = vec![0u64; 72 * n];
         let rc = unsafe { zkp_pairing_batch(self.0, g1.as_ptr(), g2.as_ptr(), opt_ptr(inf1), opt_ptr(inf2), n, out.as_mut_ptr()) };
         if rc == ZKP_OK { Ok(out) } else { Err(self.err(rc)) }
+    }
+
+    /// the same into a caller-owned output (e.g. a `PinnedVec<u64>` of 72 n limbs): no allocation, DMA both ways
+    pub fn pairing_batch_into(&mut self, g1: &[u64], g2: &[u64], inf1: Option<&[u8]>, inf2: Option<&[u8]>, out_gt: &mut [u64]) -> Result<(), Error> {
+        let n = Self::pairs(g1, g2, inf1, inf2)?;
+        if out_gt.len() != 72 * n {
+            return Err(Error { status: ZKP_ERR_ARG, detail: "out_gt does not hold 72 limbs per pair".into() });
+        }
+        let rc = unsafe { zkp_pairing_batch(self.0, g1.as_ptr(), g2.as_ptr(), opt_ptr(inf1), opt_ptr(inf2), n, out_gt.as_mut_ptr()) };
+        if rc == ZKP_OK { Ok(()) } else { Err(self.err(rc)) }
     }
 
     /// n / k Miller loop values (72 limbs each) of groups of k consecutive pairs

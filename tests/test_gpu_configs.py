@@ -161,6 +161,10 @@ def test_two_ranks_sharded_check_equals_single_rank(tmp_path):
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["config"]["pairs_per_gpu"] == 32768
     assert line["config"]["gt_sample_bit_exact"] is True and "all-reduce(MIN)" in line["config"]["workload"] and "gloo" in line["config"]["workload"]
+    # the N > 1 line carries what a bad scaling curve would be diagnosed from: every rank's own kernel time, collective time, wall time
+    detail = line["ranks_detail"]["per_rank"]
+    assert [d["rank"] for d in detail] == [0, 1] and all(d["pairs"] == 32768 and d["kernel_ms_alone"] > 0 and d["collective_ms_alone"] >= 0
+                                                         and d["step_wall_ms"] > 0 for d in detail)
     # and the guard: --gpus must match the number of ranks
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
