@@ -808,11 +808,12 @@ __device__ __forceinline__ void dbl_step(G2C& r, int c, S0&& sink_l0, S1&& sink_
     Bd<1, -33, 68> x, y, z;    // renormalised by the previous step, or a reduced input coordinate (the first step)
     x.v = r.x; y.v = r.y; z.v = r.z;
     auto zsq = bd_sqr(z, c);
-    auto nzs = bd_sqr(bd_add(z, y), c);
     auto tmp1 = bd_sqr(y, c);
-    auto nz = bd_sub(bd_sub(nzs, tmp1), zsq);
+    auto nz = bd_sub(bd_sub(bd_sqr(bd_add(z, y), c), tmp1), zsq);
+    sink_l0(bd_for_fmul(bd_dbl(bd_mul(nz, zsq, c))));
     auto tmp0 = bd_sqr(x, c);
     auto tmp4 = bd_norm(bd_add(bd_add(tmp0, tmp0), tmp0));
+    sink_l1(bd_for_fmul(bd_neg(bd_dbl(bd_mul(tmp4, zsq, c)))));
     auto tmp5 = bd_sqr(tmp4, c);
     {
         auto tmp6 = bd_sub(bd_sub(bd_sqr(bd_add(x, tmp4), c), tmp0), tmp5);
@@ -821,8 +822,6 @@ __device__ __forceinline__ void dbl_step(G2C& r, int c, S0&& sink_l0, S1&& sink_
     auto tmp3s = bd_sqr(bd_add(tmp1, x), c);
     auto tmp2 = bd_sqr(tmp1, c);
     auto tmp3 = bd_norm(bd_dbl(bd_sub(bd_sub(tmp3s, tmp0), tmp2)));
-    sink_l1(bd_for_fmul(bd_neg(bd_dbl(bd_mul(tmp4, zsq, c)))));
-    sink_l0(bd_for_fmul(bd_dbl(bd_mul(nz, zsq, c))));
     auto nx = bd_sub(bd_sub(tmp5, tmp3), tmp3);
     auto ny = bd_sub(bd_mul(bd_sub(tmp3, nx), tmp4, c), bd_norm(bd_dbl(bd_dbl(bd_dbl(tmp2)))));
     r.x = bd_vred(nx).v;
@@ -886,10 +885,13 @@ template <class S0, class S1, class S2>
 __device__ __forceinline__ void dbl_step_cln(G2C& r, int c, S0&& sink_l0, S1&& sink_l1, S2&& sink_l2) {
     Bd<1, -33, 68> x, y, w;    // renormalised by the previous step, or a reduced input coordinate / the constant 2 (the first step)
     x.v = r.x; y.v = r.y; w.v = r.z;
+    // ordered for few live values: at most six 14-register values across any by-value call (they live in the ~108 callee-saved
+    // VGPRs; what does not fit is spilled around every call)
     auto B = bd_sqr(y, c);
     auto C = bd_sqr(w, c);
     auto H2 = bd_sub(bd_sub(bd_sqr(bd_add(y, w), c), B), C);
     sink_l0(bd_for_fmul(H2));
+    auto nw = bd_dbl(bd_dbl(bd_mul(B, H2, c)));
     auto xiC = bd_xi(C, c);
     auto E = bd_vred(bd_add(bd_add(xiC, xiC), xiC));
     sink_l2(bd_for_vred(bd_dbl(bd_sub(B, E))));
@@ -904,7 +906,6 @@ __device__ __forceinline__ void dbl_step_cln(G2C& r, int c, S0&& sink_l0, S1&& s
     auto S = bd_sqr(bd_norm(bd_add(B, F)), c);
     auto T = bd_sqr(bd_dbl(E), c);
     auto ny = bd_sub(S, bd_add(bd_add(T, T), T));
-    auto nw = bd_dbl(bd_dbl(bd_mul(B, H2, c)));
     r.x = nx.v;                 // a reduced product is a valid input as it stands
     r.y = bd_vred(ny).v;
     r.z = bd_vred(nw).v;
@@ -991,10 +992,14 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
     // the neutral line (1, 0, 0)
     auto put = [&](uint32_t e, const Fp28& v) {
         if (!live_lane) return;
-        Fp28 o;
-#pragma unroll
-        for (int i = 0; i < NL; i++) o.l[i] = dead ? ((e == 0 && c == 0) ? K28_ONE[i] : 0) : v.l[i];
-        rec_store(rec(step, e + c), o);
+        if (dead) {      // a branch, not selects: as selects the limbs of ONE stay in (spilled) registers for the whole kernel
+            Fp28 o;
+            if (e == 0 && c == 0) f_set(o, K28_ONE); else f_zero(o);
+            asm volatile("" ::: "memory");
+            rec_store(rec(step, e + c), o);
+        } else {
+            rec_store(rec(step, e + c), v);
+        }
     };
     auto sink_l0 = [&](const Fp28& l0) { put(4, f_mul_v(l0, park_ld(PY))); };
     auto sink_l1 = [&](const Fp28& l1) { put(2, f_mul_v(l1, park_ld(PX))); };
@@ -1040,6 +1045,22 @@ __device__ __forceinline__ Fp28 f_vred(Fp28 a) { vred(a.l); return a; }
 
 // ---- generic Jacobian arithmetic over an "element" E with by-value ops supplied by the policy F
 //      (F1: Fp, one lane per point; F2: Fp2 spread over a lane pair)
+// the affine input point of a validity check, parked in LDS (limb quad q of value v at [(v * 4 + q) * 64 + lane])
+__device__ __forceinline__ void valid_park(int4* park, int lane, int v, const Fp28& x) {
+    park[(v * 4 + 0) * 64 + lane] = make_int4(x.l[0], x.l[1], x.l[2], x.l[3]);
+    park[(v * 4 + 1) * 64 + lane] = make_int4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    park[(v * 4 + 2) * 64 + lane] = make_int4(x.l[8], x.l[9], x.l[10], x.l[11]);
+    park[(v * 4 + 3) * 64 + lane] = make_int4(x.l[12], x.l[13], 0, 0);
+}
+__device__ __forceinline__ Fp28 valid_unpark(const int4* park, int lane, int v) {
+    asm volatile("" ::: "memory");   // keep the load at its use
+    const int4 v0 = park[(v * 4 + 0) * 64 + lane], v1 = park[(v * 4 + 1) * 64 + lane], v2 = park[(v * 4 + 2) * 64 + lane],
+               v3 = park[(v * 4 + 3) * 64 + lane];
+    Fp28 x;
+    x.l[0] = v0.x; x.l[1] = v0.y; x.l[2] = v0.z; x.l[3] = v0.w; x.l[4] = v1.x; x.l[5] = v1.y; x.l[6] = v1.z; x.l[7] = v1.w;
+    x.l[8] = v2.x; x.l[9] = v2.y; x.l[10] = v2.z; x.l[11] = v2.w; x.l[12] = v3.x; x.l[13] = v3.y;
+    return x;
+}
 struct F1 {
     int c;
     __device__ Fp28 sqr(const Fp28& a) const { return f_mul_v(a, a); }
@@ -1061,45 +1082,47 @@ struct F2 {
 struct JacP { Fp28 x, y, z; };   // z == 0 <=> infinity
 
 // a = 0 doubling (dbl-2009-l).  Infinity and y = 0 need no special case: Z3 = 2 Y Z vanishes.
+// Ordered for few live values (at most five 14-register values across any call: the by-value routines keep the caller's
+// values in the ~108 callee-saved VGPRs, anything beyond that is spilled around every call).
 template <class F>
 __device__ __forceinline__ void jac_dbl(const F& f, JacP& p) {
-    Fp28 A = f.sqr(p.x), B = f.sqr(p.y), C = f.sqr(B);
-    Fp28 D = c_sub(c_sub(f.sqr(c_add(p.x, B)), A), C);
-    D = c_dbl(D);
-    Fp28 E = c_add(c_add(A, A), A);
-    Fp28 Fq = f.sqr(E);
-    Fp28 X3 = c_sub(c_sub(Fq, D), D);
+    Fp28 B = f.sqr(p.y);
     Fp28 Z3 = c_dbl(f.mul(p.y, p.z));
+    Fp28 A = f.sqr(p.x);
+    Fp28 t = f.sqr(c_add(p.x, B));
+    Fp28 C = f.sqr(B);
+    Fp28 D = c_dbl(c_sub(c_sub(t, A), C));
+    Fp28 E = c_add(c_add(A, A), A);
+    Fp28 X3 = c_sub(c_sub(f.sqr(E), D), D);
     Fp28 Y3 = c_sub(f.mul(E, c_sub(D, X3)), c_dbl(c_dbl(c_dbl(C))));
     p.x = f_vred(X3); p.y = f_vred(Y3); p.z = f_vred(Z3);
 }
-// mixed addition p += (qx, qy) (madd-2007-bl) with every exceptional case
-template <class F>
-__device__ __forceinline__ void jac_madd(const F& f, JacP& p, const Fp28& qx, const Fp28& qy) {
-    if (f.is_zero(p.z)) { p.x = qx; p.y = qy; p.z = f.one(); return; }
+// mixed addition p += (qx, qy) (madd-2007-bl) with every exceptional case; the affine point comes through a loader (it is
+// parked in LDS: held in registers it would be ten live values across every doubling of the scalar multiplication)
+template <class F, class Q>
+__device__ __forceinline__ void jac_madd(const F& f, JacP& p, Q&& ldq) {
+    if (f.is_zero(p.z)) { p.x = ldq(0); p.y = ldq(1); p.z = f.one(); return; }
     Fp28 Z1Z1 = f.sqr(p.z);
-    Fp28 U2 = f.mul(qx, Z1Z1);
-    Fp28 S2 = f.mul(f.mul(qy, p.z), Z1Z1);
-    Fp28 H = c_sub(U2, p.x);
-    Fp28 rr = c_sub(S2, p.y);
+    Fp28 H = c_sub(f.mul(ldq(0), Z1Z1), p.x);
+    Fp28 rr = c_sub(f.mul(f.mul(ldq(1), p.z), Z1Z1), p.y);
     if (f.is_zero(H)) {
-        if (f.is_zero(rr)) { p.x = qx; p.y = qy; p.z = f.one(); jac_dbl(f, p); return; }
+        if (f.is_zero(rr)) { p.x = ldq(0); p.y = ldq(1); p.z = f.one(); jac_dbl(f, p); return; }
         f_zero(p.z);   // P + (-P)
         return;
     }
-    rr = c_dbl(rr);
     Fp28 HH = f.sqr(H);
+    Fp28 Z3 = c_sub(c_sub(f.sqr(c_add(p.z, H)), Z1Z1), HH);
+    rr = c_dbl(rr);
     Fp28 I = c_dbl(c_dbl(HH));
-    Fp28 J = f.mul(H, I);
     Fp28 V = f.mul(p.x, I);
+    Fp28 J = f.mul(H, I);
     Fp28 X3 = c_sub(c_sub(c_sub(f.sqr(rr), J), V), V);
     Fp28 Y3 = c_sub(f.mul(rr, c_sub(V, X3)), c_dbl(f.mul(p.y, J)));
-    Fp28 Z3 = c_sub(c_sub(f.sqr(c_add(p.z, H)), Z1Z1), HH);
     p.x = f_vred(X3); p.y = f_vred(Y3); p.z = f_vred(Z3);
 }
-// p = [k] (qx, qy), k given as nwords 64-bit words, MSB first
-template <class F>
-__device__ __forceinline__ void jac_mul(const F& f, JacP& p, const Fp28& qx, const Fp28& qy, const uint64_t* k, int nwords) {
+// p = [k] Q, Q behind the loader, k given as nwords 64-bit words, MSB first
+template <class F, class Q>
+__device__ __forceinline__ void jac_mul(const F& f, JacP& p, Q&& ldq, const uint64_t* k, int nwords) {
     p.x = f.one(); p.y = f.one(); f_zero(p.z);
 #pragma unroll 1
     for (int w = nwords - 1; w >= 0; w--) {
@@ -1107,7 +1130,7 @@ __device__ __forceinline__ void jac_mul(const F& f, JacP& p, const Fp28& qx, con
 #pragma unroll 1
         for (int b = 63; b >= 0; b--) {
             jac_dbl(f, p);
-            if ((e >> b) & 1) jac_madd(f, p, qx, qy);
+            if ((e >> b) & 1) jac_madd(f, p, ldq);
         }
     }
 }
@@ -1135,10 +1158,15 @@ __global__ void __launch_bounds__(64, 2) k_g1_valid28(const uint64_t* g1, const 
     Fp28 rhs = c_add(f.mul(f.sqr(x), x), f_const(K28_B));
     if (!f.is_zero(c_sub(lhs, rhs))) { status[i] = 1; return; }
     const uint64_t x2[2] = {0x0000000100000000ULL, 0xac45a4010001a402ULL};   // X^2, X = 0xd201000000010000
+    __shared__ int4 park[2 * 4 * 64];
+    const int lane = threadIdx.x;
+    valid_park(park, lane, 0, x);
+    valid_park(park, lane, 1, y);
+    auto ldq = [&](int v) -> Fp28 { return valid_unpark(park, lane, v); };
     JacP p;
-    jac_mul(f, p, x, y, x2, 2);
-    Fp28 bx = f.mul(x, f_const(K28_BETA));
-    status[i] = jac_eq_affine(f, p, bx, c_neg(y)) ? 0 : 2;
+    jac_mul(f, p, ldq, x2, 2);
+    Fp28 bx = f.mul(ldq(0), f_const(K28_BETA));
+    status[i] = jac_eq_affine(f, p, bx, c_neg(ldq(1))) ? 0 : 2;
 }
 
 // two lanes per point: psi(P) == -[X]P  (src/g2.rs:166-170)
@@ -1149,6 +1177,8 @@ __global__ void __launch_bounds__(64, 2) k_g2_valid28(const uint64_t* g2, const 
     const bool live = i < n;
     if (!live) i = n - 1;
     const bool is_inf = inf && inf[i];
+    __shared__ int4 park[2 * 4 * 64];
+    const int lane = threadIdx.x;
     F2 f{c};
     Fp28 x, y;
     fp28_from_wire(x, g2 + 24 * (size_t)i + 6 * c);
@@ -1160,8 +1190,12 @@ __global__ void __launch_bounds__(64, 2) k_g2_valid28(const uint64_t* g2, const 
         st = 1;
     } else {
         const uint64_t xs[1] = {0xd201000000010000ULL};
+        valid_park(park, lane, 0, x);
+        valid_park(park, lane, 1, y);
+        auto ldq = [&](int v) -> Fp28 { return valid_unpark(park, lane, v); };
         JacP p;
-        jac_mul(f, p, x, y, xs, 1);
+        jac_mul(f, p, ldq, xs, 1);
+        x = ldq(0); y = ldq(1);
         // psi(P) = (conj(x) PSI_X, conj(y) PSI_Y); compare [X]P with (psi_x, -psi_y)
         Fp28 cx = c ? c_neg(x) : x, cy = c ? c_neg(y) : y;
         Fp28 kx = f_const(c ? K28_PSI_X_1 : K28_PSI_X_0), ky = f_const(c ? K28_PSI_Y_1 : K28_PSI_Y_0);
@@ -1323,8 +1357,13 @@ __global__ void __launch_bounds__(64, 2) k_g1_mul28(const uint64_t* base, size_t
     fp28_from_wire(x, base + stride * i);
     fp28_from_wire(y, base + stride * i + 6);
     const uint64_t k[4] = {sc[4 * (size_t)i], sc[4 * (size_t)i + 1], sc[4 * (size_t)i + 2], sc[4 * (size_t)i + 3]};
+    __shared__ int4 park[2 * 4 * 64];
+    const int lane = threadIdx.x;
+    valid_park(park, lane, 0, x);
+    valid_park(park, lane, 1, y);
+    auto ldq = [&](int v) -> Fp28 { return valid_unpark(park, lane, v); };
     JacP p;
-    jac_mul(f, p, x, y, k, 4);
+    jac_mul(f, p, ldq, k, 4);
     const bool inf = f.is_zero(p.z);
     Fp28 zi = f_inv(p.z);
     Fp28 zi2 = f.sqr(zi);
@@ -1345,8 +1384,13 @@ __global__ void __launch_bounds__(64, 2) k_g2_mul28(const uint64_t* base, size_t
     fp28_from_wire(x, base + stride * i + 6 * c);
     fp28_from_wire(y, base + stride * i + 12 + 6 * c);
     const uint64_t k[4] = {sc[4 * (size_t)i], sc[4 * (size_t)i + 1], sc[4 * (size_t)i + 2], sc[4 * (size_t)i + 3]};
+    __shared__ int4 park[2 * 4 * 64];
+    const int lane = threadIdx.x;
+    valid_park(park, lane, 0, x);
+    valid_park(park, lane, 1, y);
+    auto ldq = [&](int v) -> Fp28 { return valid_unpark(park, lane, v); };
     JacP p;
-    jac_mul(f, p, x, y, k, 4);
+    jac_mul(f, p, ldq, k, 4);
     const bool inf = f.is_zero(p.z);
     // 1 / (z0 + z1 u) = (z0 - z1 u) / (z0^2 + z1^2)   (reference src/fp2.rs:278-296); both lanes invert the norm
     Fp28 o;
