@@ -298,6 +298,95 @@ def generate(vb=8):
     return g, out
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# k_ksq: one Fp2 product per lane and compressed squaring, (xr + xi u)(yr + yi u) = (xr yr - xi yi) + (xr yi + xi yr) u, each
+# coefficient ONE lazy accumulation of two Karatsuba products and one reduction - the MULACC step's term and tail on operands that
+# sit in registers (no LDS, no tables).  It replaces two product-scanning multiplies (mont_mul_ps, 2 x 602 multiply-adds): 4 x 147 +
+# 2 x 196 = 980 multiply-adds, the same limbs (the columns are the same integers mod 2^64).
+class Fp2Mul:
+    def __init__(self, vb):
+        self.lines = []
+        self.vb = vb
+        v = vb
+        assert v % 2 == 0
+        self.XR = v; v += 14          # in: xr; out: the real part
+        self.XI = v; v += 14          # in: xi; out: dead (holds -xi)
+        self.YR = v; v += 14          # in
+        self.YI = v; v += 14          # in
+        self.S = v; v += 14           # out: the imaginary part
+        self.D = v; v += 14           # Karatsuba differences / tail temporaries
+        self.ACC = {}
+        for k in range(27):
+            if k == 13:
+                continue
+            self.ACC[k] = v; v += 2
+        self.MID = {}
+        for k in range(13):
+            self.MID[k] = v; v += 2
+        self.vend = v
+        self.sb = 36
+        self.sC = 36
+        self.send = 38
+
+    e = Asm.e
+    mad = Asm.mad
+
+
+def kterm(g, A, B, first):
+    """acc (+)= A * B, 14-limb operands in registers, one level of Karatsuba (147 multiply-adds + 14 subtractions)"""
+    D = g.D
+    for i in range(NH):
+        g.e("v_sub_u32 v%d, v%d, v%d" % (D + i, A + NH + i, A + i))
+    for i in range(NH):
+        g.e("v_sub_u32 v%d, v%d, v%d" % (D + NH + i, B + i, B + NH + i))
+    touched = set()
+
+    def acc(reg_key, dst, a, b):
+        add = dst
+        if first and reg_key not in touched:
+            add = None
+            touched.add(reg_key)
+        g.mad(dst, vreg(a), vreg(b), add)
+
+    for j in range(NH):
+        for i in range(NH):
+            acc(("a", i + j), g.ACC[i + j], A + i, B + j)
+            acc(("a", NL + i + j), g.ACC[NL + i + j], A + NH + i, B + NH + j)
+            acc(("m", i + j), g.MID[i + j], D + i, D + NH + j)
+
+
+def generate_fp2mul(vb=6):
+    g = Fp2Mul(vb)
+    kterm(g, g.XR, g.YI, True)
+    kterm(g, g.XI, g.YR, False)
+    tail(g, g.S)
+    for i in range(NL):
+        g.e("v_sub_u32 v%d, 0, v%d" % (g.XI + i, g.XI + i))
+    kterm(g, g.XR, g.YR, True)
+    kterm(g, g.XI, g.YI, False)
+    tail(g, g.XR)
+    return g
+
+
+def write_fp2mul(f, vb=6):
+    g = generate_fp2mul(vb)
+    n = sum(1 for l in g.lines if not l.endswith(":"))
+    f.write("// The Fp2 product of k_ksq: %d instructions; VGPRs v%d..v%d.\n" % (n, g.vb, g.vend - 1))
+    f.write("#define ZKP_FP2MUL_ASM \\\n")
+    for l in g.lines:
+        f.write('    "%s\\n\\t" \\\n' % l)
+    f.write('    ""\n')
+    f.write("// operands: xr (in) / real part (out), xi (in, destroyed), the imaginary part (out); then the inputs yr, yi\n")
+    f.write("#define ZKP_FP2MUL_OUTS(xr, xi, sim) " + ", ".join('"+{v%d}"((xr)[%d])' % (g.XR + i, i) for i in range(NL)) + ", "
+            + ", ".join('"+{v%d}"((xi)[%d])' % (g.XI + i, i) for i in range(NL)) + ", "
+            + ", ".join('"={v%d}"((sim)[%d])' % (g.S + i, i) for i in range(NL)) + "\n")
+    f.write("#define ZKP_FP2MUL_INS(yr, yi) " + ", ".join('"{v%d}"((yr)[%d])' % (g.YR + i, i) for i in range(NL)) + ", "
+            + ", ".join('"{v%d}"((yi)[%d])' % (g.YI + i, i) for i in range(NL)) + "\n")
+    f.write("#define ZKP_FP2MUL_CLOBBERS " + ", ".join('"v%d"' % v for v in range(g.D, g.vend)) + ", "
+            + ", ".join('"s%d"' % x for x in range(g.sb, g.send)) + ', "scc"\n')
+    return g
+
+
 def write_inc(path, vb=8):
     g, out = generate(vb)
     outs = list(range(out, out + NL))
@@ -314,6 +403,7 @@ def write_inc(path, vb=8):
         f.write('    ""\n')
         f.write("#define ZKP_MULACC_OUTS(r) " + ", ".join('"={v%d}"((r)[%d])' % (outs[i], i) for i in range(NL)) + "\n")
         f.write("#define ZKP_MULACC_CLOBBERS " + ", ".join('"v%d"' % v for v in vclob) + ", " + ", ".join('"s%d"' % s for s in sclob) + ', "scc", "memory"\n')
+        write_fp2mul(f)
     return g
 
 

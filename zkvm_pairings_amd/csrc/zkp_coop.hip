@@ -489,7 +489,9 @@ __device__ __forceinline__ void park_ld(int32_t* re, int32_t* im, const int4* xc
     im[8] = i2.x; im[9] = i2.y; im[10] = i2.z; im[11] = i2.w;
 }
 // out = 3 t + 2 sgn x - q p (sgn = -1 where neg is all ones) with q = round(value / p) taken from the top limbs, as ONE
-// exact carry chain (balanced limbs, the top limb keeps the rest); |result| < 0.51 p
+// exact carry chain (balanced limbs, the top limb keeps the rest); |result| < 0.51 p.  (The chain stays in 64 bits: t is a
+// combination of three products, |limb| <= 4 * 2^27, so 3 t + 2 x - q p reaches 20 * 2^27 - a 32-bit chain was measured 1.5 %
+// faster on the pass and WRONG, round 3.)
 __device__ __forceinline__ void sq_combine(int32_t* out, const int32_t* t, const int32_t* x, int32_t neg) {
     int32_t sx[NL];
 #pragma unroll
@@ -513,8 +515,16 @@ __device__ __forceinline__ void sq_combine(int32_t* out, const int32_t* t, const
 }
 #define ZKP_QUAD(x, ctrl) __builtin_amdgcn_update_dpp(0, (x), (ctrl), 0xf, 0xf, false)
 
+#ifndef ZKP_KSQ_ASM
+#define ZKP_KSQ_ASM ZKP_COOP_ASM   // the Fp2 product of k_ksq as the interpreter's Karatsuba term + tail on register operands (tools/coopasm.py:
+                                   // 980 multiply-adds instead of the 1,204 of two product-scanning multiplies); 0: mont_mul_ps, the A/B baseline
+#endif
 #ifndef ZKP_KSQ_WAVES
+#if ZKP_KSQ_ASM
+#define ZKP_KSQ_WAVES 3            // the block pins 162 VGPRs (four operands, both results' homes, 78 accumulator registers)
+#else
 #define ZKP_KSQ_WAVES 4
+#endif
 #endif
 // nsq compressed squarings of the Fp12 value in state elements [elem_in, elem_in + 12) (only z2..z5 are read); after
 // squaring number it + 1 where bit it of snap_mask is set, (z2..z5) go to the next snapshot area: 12 elements each from
@@ -564,10 +574,25 @@ __global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t
     for (uint32_t it = 0; it < nsq; it++) {
         int32_t sre[NL], sim[NL];
         // X Y = (X0 Y0 - X1 Y1) + (X0 Y1 + X1 Y0) u, one reduction per coefficient
+#if ZKP_KSQ_ASM
+        {
+            constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};
+            asm volatile(ZKP_FP2MUL_ASM
+                         : ZKP_FP2MUL_OUTS(xr, xi, sim)
+                         : ZKP_FP2MUL_INS(yr, yi),
+                           [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]), [p6] "s"(PL[6]),
+                           [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]), [p12] "s"(PL[12]),
+                           [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)
+                         : ZKP_FP2MUL_CLOBBERS);
+#pragma unroll
+            for (int i = 0; i < NL; i++) sre[i] = xr[i];     // the block leaves the real part in xr's registers
+        }
+#else
         mont_mul_ps<true>(sim, xr, yi, xi, yr);
 #pragma unroll
         for (int i = 0; i < NL; i++) xi[i] = -xi[i];
         mont_mul_ps<true>(sre, xr, yr, xi, yi);
+#endif
         // the other pair's products: A from its even lane, B from its odd lane.  The DPP reads stay outside the lane-role
         // branches: a DPP read from a lane that the branch has switched off returns nothing.
         int32_t tr[NL], ti[NL];
@@ -601,6 +626,15 @@ __global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t
 #pragma unroll
         for (int i = 0; i < NL; i++) { pr[i] = ZKP_QUAD(sre[i], 0xB1); pi[i] = ZKP_QUAD(sim[i], 0xB1); }   // quad_perm [1,0,3,2]
         if (it < 64 && ((snap_mask >> it) & 1)) {      // wave-uniform (a 64-bit shift by 64 or more is undefined)
+#if ZKP_KSQ_ASM
+            // the record pointer is re-derived here from an opaque copy of the lane number: kept in registers across the asm block
+            // (which owns 162 of the 168 VGPRs) it would be spilled and reloaded in every squaring, for six uses per run
+            int l_ = lane;
+            asm volatile("" : "+v"(l_));
+            const uint32_t chk_ = blockIdx.x * KS_CHECKS + (l_ >> 2);
+            int4* const st_ = state + (size_t)(chk_ < n_checks ? chk_ : n_checks - 1) * 4;
+            auto rec = [&](uint32_t e) -> int4* { return st_ + (size_t)e * nc * 4; };
+#endif
             if (active && !b_lane) {      // lane 0 holds (v, u) = (mine, partner), lane 2 (u, v)
                 Fp28 o;
 #pragma unroll
