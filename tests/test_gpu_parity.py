@@ -535,6 +535,43 @@ def test_host_pointer_entry_points_in_slices(monkeypatch):
         e.close()
 
 
+def test_page_locked_host_arrays(monkeypatch):
+    """the host-pointer entry points from page-locked memory (zkp_host_alloc through PairingEngine.host_array, and a numpy array
+    page-locked in place with zkp_host_register): same Gt and flags as from pageable arrays, sliced pipeline included, caller-owned
+    page-locked output; the memory comes back (zkp_host_free / zkp_host_unregister) without error"""
+    import ctypes
+    from zkvm_pairings_amd import PairingEngine, _lib, synthetic
+    monkeypatch.setenv("ZKP_HOST_SLICE", "128")
+    e = PairingEngine(0)
+    try:
+        n = 777
+        g1, g2, _, _ = synthetic.random_pairs(e, n, seed=99)
+        want = e.pairing(g1, g2)
+        assert np.array_equal(want[:64], o.pairing_batch(g1[:64], g2[:64], nthreads=NTHREADS))
+        p1, p2, pg = e.host_array((n, 12)), e.host_array((n, 24)), e.host_array((n, 72))
+        p1[:], p2[:] = g1, g2
+        got = e.pairing(p1, p2, out=pg)
+        assert got is pg and np.array_equal(pg, want)
+        ok, allok = e.pairing_check(p1, p2, 1)
+        assert not ok.any() and not allok
+        with pytest.raises(ValueError):
+            e.pairing(p1, p2, out=np.empty((n, 71), dtype=np.uint64))
+        lib = _lib.load()
+        r1, r2 = np.array(g1), np.array(g2)
+        assert lib.zkp_host_register(ctypes.c_void_p(r1.ctypes.data), r1.nbytes) == 0
+        assert lib.zkp_host_register(ctypes.c_void_p(r2.ctypes.data), r2.nbytes) == 0
+        try:
+            assert np.array_equal(e.pairing(r1, r2), want)
+        finally:
+            assert lib.zkp_host_unregister(ctypes.c_void_p(r1.ctypes.data)) == 0
+            assert lib.zkp_host_unregister(ctypes.c_void_p(r2.ctypes.data)) == 0
+        p = ctypes.c_void_p()
+        assert lib.zkp_host_alloc(0, ctypes.byref(p)) == -1 and lib.zkp_host_free(None) == 0      # ZKP_ERR_ARG; free(NULL) is a no-op
+        del p1, p2, pg, got
+    finally:
+        e.close()
+
+
 def test_divstep_inversion_equals_fermat(monkeypatch):
     """the final exponentiation's Fp inversion: division steps (default) against a^(p-2) (ZKP_COOP_INV_FERMAT=1) on the
     same inputs, one check per lane and several per lane; zero inputs give the same (unspecified but equal) results"""
