@@ -183,9 +183,9 @@ def term(g, p, first, tag):
     g.e("s_cmp_ge_u32 s%d, %%[T]" % g.sN)
     g.e("s_cbranch_scc1 %s_nopre2" % L)
     second_fetch(g, L, g.sN)
-    g.e("s_add_u32 s%d, s%d, 0x400" % (g.sRT, g.sRT))
+    g.e("s_add_u32 s%d, s%d, %%[row]" % (g.sRT, g.sRT))
     g.e("s_addc_u32 s%d, s%d, 0" % (g.sRT + 1, g.sRT + 1))
-    g.e("global_load_dwordx3 v[%d:%d], %%[lane16], s[%d:%d] offset:1024" % (g.E, g.E + 2, g.sRT, g.sRT + 1))
+    g.e("global_load_dwordx3 v[%d:%d], %%[lane16], s[%d:%d] offset:%%[row]" % (g.E, g.E + 2, g.sRT, g.sRT + 1))
     g.e("%s_nopre2:" % L)
     for j in range(NH):
         for i in range(NH):
@@ -267,7 +267,7 @@ def generate(vb=8):
     out = g.A[0]
     # prologue: per-step flag words (row T of the resolved table), entry of term 0, operands of term 0, entry of term 1
     g.e("s_mov_b64 s[%d:%d], %%[rt]" % (g.sRT, g.sRT + 1))
-    g.e("s_lshl_b32 s%d, %%[T], 10" % g.sX)
+    g.e("s_mul_i32 s%d, %%[T], %%[row]" % g.sX)       # row: bytes per table row (64 lanes x 16 B x wavefronts per workgroup)
     g.e("s_add_u32 s%d, s%d, s%d" % (g.sX, g.sRT, g.sX))
     g.e("s_addc_u32 s%d, s%d, 0" % (g.sX + 1, g.sRT + 1))
     g.e("global_load_dwordx3 v[%d:%d], %%[lane16], s[%d:%d]" % (g.E, g.E + 2, g.sRT, g.sRT + 1))
@@ -277,7 +277,7 @@ def generate(vb=8):
     ds_read_rec(g, g.A[0], vreg(g.E))
     ds_read_rec(g, g.B[0], vreg(g.E + 1))
     second_fetch(g, ".Lmp_%=", g.sT)
-    g.e("global_load_dwordx3 v[%d:%d], %%[lane16], s[%d:%d] offset:1024" % (g.E, g.E + 2, g.sRT, g.sRT + 1))
+    g.e("global_load_dwordx3 v[%d:%d], %%[lane16], s[%d:%d] offset:%%[row]" % (g.E, g.E + 2, g.sRT, g.sRT + 1))
     term(g, 0, True, "a")
     g.e("s_add_u32 s%d, s%d, 1" % (g.sT, g.sT))
     g.e("s_cmp_ge_u32 s%d, %%[T]" % g.sT)

@@ -48,7 +48,17 @@ using namespace zkp28;
 
 namespace {
 
-constexpr int GROUPS = 5;              // checks per wavefront
+#ifndef ZKP_COOP_WG_WAVES
+#define ZKP_COOP_WG_WAVES 1   // wavefronts per k_coop workgroup: 1 = five checks per wavefront, lanes 60..63 idle; 3 = sixteen checks per
+                              // workgroup - lanes 60..63 of the three wavefronts together run the sixteenth check, and every step that
+                              // touches LDS is fenced by workgroup barriers (its operand reads before its in-place result store, its
+                              // stores before the next step's reads).  Bit-exact and measured: 6.25 % fewer
+                              // wavefronts, but they spend 21 % of their cycles at the barriers - the Miller program alone runs 12 %
+                              // slower, the 2^20-pair pass the same (256.8 against 256.0 ms).  Kept as a build knob.
+#endif
+constexpr int WGW = ZKP_COOP_WG_WAVES;
+static_assert(WGW == 1 || WGW == 3, "one wavefront (5 checks) or three (16 checks) per workgroup");
+constexpr int GROUPS = WGW == 3 ? 16 : 5;   // checks per workgroup
 constexpr int LIG = ZKP_COOP_G;        // 12 lanes per group
 constexpr int ST_SIZE = ZKP_COOP_ST_SIZE;
 constexpr int NLINES = ZKP_COOP_NLINES;
@@ -132,7 +142,8 @@ __device__ __forceinline__ void canon28(uint32_t* f, const int32_t* x) {
 }
 
 __host__ __device__ constexpr int coop_group_stride(int S) { return S + ((4 - S % 8) + 8) % 8; }
-constexpr size_t coop_lds_bytes(int S, int SC) { return (size_t)4 * (SC + GROUPS * coop_group_stride(S)) * 16; }
+// (+ 16 bytes behind the image with three wavefronts: the identity flags of the check that straddles them)
+constexpr size_t coop_lds_bytes(int S, int SC) { return (size_t)4 * (SC + GROUPS * coop_group_stride(S)) * 16 + (WGW > 1 ? 16 : 0); }
 #ifndef ZKP_COOP_KARATSUBA
 #define ZKP_COOP_KARATSUBA 1   // acc_mul_k: 147 multiply-adds per product block instead of 196 (zkp_fp28.hpp); measured on one box,
                                // 2^20-pair pass: 296.5 ms -> 283.3 ms
@@ -150,9 +161,9 @@ constexpr size_t coop_lds_bytes(int S, int SC) { return (size_t)4 * (SC + GROUPS
 // S slots per group and SC constants: two instantiations - <24, 34> for programs that need the whole constants table (11,136 B of
 // LDS per wavefront), <30, 4> for the Miller programs (30 slots, 4 constants; 11,776 B); twelve wavefronts per CU either way
 template <int S, int SC>
-__global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
+__global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     extern __shared__ int4 lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x;        // 0 .. 64 * WGW - 1: the lane number within the workgroup
     // per-lane values, all functions of the lane number.  With the asm MULACC block (ZKP_COOP_ASM) they are re-derived at the top of
     // every step and again behind the block from an opaque copy of `lane` (ZKP_LANE_CTX): kept in registers across the block they
     // would cost the kernel its third wavefront per SIMD (the block owns 156 of the 168 VGPRs)
@@ -175,15 +186,26 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     do {                                                                                                \
         int l_ = lane;                                                                                  \
         ZKP_LANE_OPAQUE(l_);                                                                            \
-        grp = (l_ * 43) >> 9;             /* lane / 12 for lane < 64 */                                 \
-        lig = l_ - grp * LIG;             /* lanes 60..63: grp 5, lig 0..3 (never store) */             \
-        lane_ok = grp < GROUPS;                                                                         \
+        if (WGW == 1) {                                                                                 \
+            grp = (l_ * 43) >> 9;             /* lane / 12 for lane < 64 */                             \
+            lig = l_ - grp * LIG;             /* lanes 60..63: grp 5, lig 0..3 (never store) */         \
+            lane_ok = grp < GROUPS;                                                                     \
+        } else {                              /* wavefront w: checks 5w .. 5w+4; its lanes 60..63 are lanes 4w .. 4w+3 of check 15 */ \
+            const int wv_ = l_ >> 6, wl_ = l_ & 63, g0_ = (wl_ * 43) >> 9;                              \
+            grp = g0_ < 5 ? wv_ * 5 + g0_ : 15;                                                         \
+            lig = g0_ < 5 ? wl_ - g0_ * LIG : wv_ * 4 + (wl_ - 60);                                     \
+            lane_ok = true;                                                                             \
+        }                                                                                               \
         check = blockIdx.x * GROUPS + grp;                                                              \
         active = lane_ok && check < A.n_checks;                                                         \
         gbase = SC + (lane_ok ? grp : GROUPS - 1) * SG;                                                 \
     } while (0)
+    // with several wavefronts per workgroup one check's lanes sit in all of them: LDS reads and writes of a step are fenced
+// (LDS counter only: a global load in flight need not land before the barrier)
+#define ZKP_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define ZKP_WG_FENCE() do { if (WGW > 1) ZKP_WG_BARRIER(); } while (0)
 
-    for (int i = lane; i < (int)A.nconst * 4; i += 64) lds[(i & 3) * PS + (i >> 2)] = A.consts[i];
+    for (int i = lane; i < (int)A.nconst * 4; i += 64 * WGW) lds[(i & 3) * PS + (i >> 2)] = A.consts[i];
     __syncthreads();
 
     // the step headers are read-only and wave-uniform: through the constant address space they become scalar loads
@@ -211,7 +233,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             // addresses, Karatsuba fold, row-pipelined Montgomery reduction, limb extraction; the same integers as
             // acc_mul_k / acc_fold / acc_reduce of the C++ variant below
             const uint32_t ew = tbl[off + T * LIG + lig];
-            const uint4* rt = A.rtbl + (size_t)(off / LIG) * 64;
+            const uint4* rt = A.rtbl + (size_t)(off / LIG) * (64 * WGW);
             int32_t r[NL];
             {
                 static_assert(NL == 14, "the generated block is for 14 limbs");
@@ -219,7 +241,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 asm volatile(ZKP_MULACC_ASM
                              : ZKP_MULACC_OUTS(r)
                              : [rt] "s"(rt), [T] "s"(T), [h1] "s"(h1), [h3] "s"(h3), [lane16] "v"(lane * 16),   // (rematerialised from the lane number: not a live value)
-                               [ps1] "i"(PS * 16), [ps2] "i"(PS * 32), [ps3] "i"(PS * 48),
+                               [ps1] "i"(PS * 16), [ps2] "i"(PS * 32), [ps3] "i"(PS * 48), [row] "i"(1024 * WGW),
                                [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]), [p6] "s"(PL[6]),
                                [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]), [p12] "s"(PL[12]),
                                [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)
@@ -302,6 +324,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             if (h1 & 1) {  // step-uniform: epilogue dst = alpha r + beta E, renormalised
                 int32_t e[NL];
                 ld(e, (ew >> 16) & 127);
+                ZKP_WG_FENCE();   // every operand of the step has been read
                 const int32_t al = sext4((ew >> 8) & 15), be = sext4((ew >> 12) & 15);
                 // value renormalisation folded in: q = round(value / p) from the top limb of the combination
                 // (the lower limbs are normalised: their carries cannot move q), then ONE weak normalisation
@@ -310,6 +333,8 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
 #pragma unroll
                 for (int i = 0; i < NL; i++) r[i] = al * r[i] + be * e[i] - q * K_PBAL[i];
                 weak_norm(r);
+            } else {
+                ZKP_WG_FENCE();
             }
             if (active && ((ew >> 7) & 1)) lds_st(lds, gbase + (int)(ew & 63), PS, r);
             if (h1 & 2) {  // step-uniform: companion store of a squaring run - the even lane of an Fp2 coefficient keeps
@@ -323,6 +348,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 }
                 if (active && ((ew >> 29) & 1)) lds_st(lds, gbase + (int)((ew >> 23) & 63), PS, c2);
             }
+            ZKP_WG_FENCE();
         } else if (op == OP_LIN) {
             int32_t r[NL];
 #pragma unroll
@@ -339,7 +365,9 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             weak_norm(r);
             if (h1 & 1) vred(r);   // only where the generator's static value bound asks for it
             const uint32_t ew = tbl[off + arg * LIG + lig];
+            ZKP_WG_FENCE();
             if (active && ((ew >> 7) & 1)) lds_st(lds, gbase + (int)(ew & 63), PS, r);
+            ZKP_WG_FENCE();
         } else if (op == OP_GLOAD) {
             const uint32_t w = tbl[off + lig];
             const uint32_t idx = w >> 8;
@@ -368,6 +396,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 }
                 lds_st(lds, gbase + (int)(w & 63), PS, x);
             }
+            ZKP_WG_FENCE();
             cursor += h1;
         } else if (op == OP_GSTORE) {
             const uint32_t w = tbl[off + lig];
@@ -403,7 +432,16 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
 #pragma unroll
                     for (int i = 1; i < NL; i++) d |= f[i];
                     const unsigned long long good = __ballot((d == 0) || !part);
-                    const unsigned gm = (unsigned)((good >> (grp * LIG)) & 0xfffu);
+                    unsigned gm;
+                    if (WGW == 1) {
+                        gm = (unsigned)((good >> (grp * LIG)) & 0xfffu);
+                    } else {   // check 15: four lanes in each wavefront, their flags meet behind the LDS image
+                        uint32_t* tailf = (uint32_t*)(lds + 4 * PS);
+                        const int wv = lane >> 6, g0 = ((lane & 63) * 43) >> 9;
+                        if ((lane & 63) == 60) tailf[wv] = (uint32_t)(good >> 60) & 0xfu;
+                        __syncthreads();
+                        gm = g0 < 5 ? (unsigned)((good >> (g0 * LIG)) & 0xfffu) : (tailf[0] | tailf[1] << 4 | tailf[2] << 8);
+                    }
                     if (active && lig == 0) {
                         const bool is_one = gm == 0xfffu;
                         if (A.ok) A.ok[check] = is_one ? 1 : 0;
@@ -411,6 +449,7 @@ __global__ void __launch_bounds__(64, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                     }
                 }
             }
+            ZKP_WG_FENCE();   // a GLOAD step behind this one stores without a fence of its own
         } else if (op == OP_LOOP) {
             loop_pc = pc + 1;
             loop_left = (int)h1;
@@ -1651,23 +1690,30 @@ static void coop_resolve_table(const ZkpProgDesc& p, std::vector<uint4>& rt) {
     const int S = p.wide ? ZKP_COOP_WIDE_NSLOT : ZKP_COOP_NSLOT, SC = p.wide ? ZKP_COOP_WIDE_NCONST : ZKP_COOP_NCONST;
     const int SG = coop_group_stride(S);
     const size_t rows = p.n_tbl / LIG + 2;
-    rt.assign(rows * 64, make_uint4(0, 0, 0, 0));
+    constexpr int RL = 64 * WGW;   // lanes per row
+    rt.assign(rows * RL, make_uint4(0, 0, 0, 0));
     auto addr = [&](uint32_t slot, int grp) -> uint32_t { return 16u * (((slot & 64) ? 0 : SC + grp * SG) + (slot & 63)); };
     for (uint32_t pc = 0; pc * 4 + 3 < p.n_hdr; pc++) {
         const uint32_t h0 = p.hdr[4 * pc], off = p.hdr[4 * pc + 2];
         if ((h0 & 0xff) != OP_MULACC) continue;
         const uint32_t T = (h0 >> 8) & 0xff;
-        for (int lane = 0; lane < 64; lane++) {
-            const int g0 = lane / LIG, lig = lane - g0 * LIG, grp = g0 < GROUPS ? g0 : GROUPS - 1;
+        for (int lane = 0; lane < RL; lane++) {
+            int g0 = lane / LIG, lig = lane - g0 * LIG, grp = g0 < GROUPS ? g0 : GROUPS - 1;
+            if (WGW > 1) {
+                const int wv = lane >> 6, wl = lane & 63;
+                g0 = wl / LIG;
+                grp = g0 < 5 ? wv * 5 + g0 : 15;
+                lig = g0 < 5 ? wl - g0 * LIG : wv * 4 + (wl - 60);
+            }
             uint32_t f1 = 0, f2 = 0;
             for (uint32_t t = 0; t < T; t++) {
                 const uint32_t w = p.tbl[off + t * LIG + lig];
-                rt[(off / LIG + t) * 64 + lane] =
+                rt[(off / LIG + t) * RL + lane] =
                     make_uint4(addr(w & 127, grp), addr((w >> 14) & 127, grp), addr((w >> 7) & 127, grp) | (addr((w >> 21) & 127, grp) << 16), 0);
                 f1 |= ((w >> 30) & 1) << t | ((w >> 31) & 1) << (12 + t);
                 f2 |= ((w >> 28) & 1) << t | ((w >> 29) & 1) << (12 + t);
             }
-            rt[(off / LIG + T) * 64 + lane] = make_uint4(f1, f2, 0, 0);
+            rt[(off / LIG + T) * RL + lane] = make_uint4(f1, f2, 0, 0);
         }
     }
 }
@@ -1790,16 +1836,17 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     a.chk_off = chk_off;
 
     const size_t lds_plain = coop_lds_bytes(ZKP_COOP_NSLOT, ZKP_COOP_NCONST), lds_wide = coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST);
-    static_assert(12 * coop_lds_bytes(ZKP_COOP_NSLOT, ZKP_COOP_NCONST) <= 160 * 1024 && 12 * coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST) <= 160 * 1024,
+    static_assert(12 / WGW * coop_lds_bytes(ZKP_COOP_NSLOT, ZKP_COOP_NCONST) <= 160 * 1024 &&
+                      12 / WGW * coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST) <= 160 * 1024,
                   "twelve wavefronts (three per SIMD, the register bound) must fit the 160 KB of LDS of a CU");
     size_t lds_bytes = wide ? lds_wide : lds_plain;
     static const char* pad_env = getenv("ZKP_COOP_LDS_PAD");   // occupancy experiments only
     if (pad_env) lds_bytes += (size_t)atol(pad_env);
     unsigned blocks = (n_checks + GROUPS - 1) / GROUPS;
     if (wide)
-        hipLaunchKernelGGL((k_coop<ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST>), dim3(blocks), dim3(64), lds_bytes, s, a);
+        hipLaunchKernelGGL((k_coop<ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST>), dim3(blocks), dim3(64 * WGW), lds_bytes, s, a);
     else
-        hipLaunchKernelGGL((k_coop<ZKP_COOP_NSLOT, ZKP_COOP_NCONST>), dim3(blocks), dim3(64), lds_bytes, s, a);
+        hipLaunchKernelGGL((k_coop<ZKP_COOP_NSLOT, ZKP_COOP_NCONST>), dim3(blocks), dim3(64 * WGW), lds_bytes, s, a);
     return hipGetLastError();
 }
 
