@@ -702,6 +702,11 @@ __device__ __forceinline__ void swap_pair(Fp28& o, const Fp28& x) {
 #pragma unroll
     for (int i = 0; i < NL; i++) o.l[i] = __builtin_amdgcn_update_dpp(0, x.l[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
 }
+#ifndef ZKP_PREP_KARATSUBA
+#define ZKP_PREP_KARATSUBA 0   // Karatsuba product blocks (147 multiply-adds instead of 196) in the by-value routines: bit-exact, measured
+                               // round 3: k_prep_lines<true> 8.03-8.16 against 8.08-8.09 ms per 2^18 pairs - the 13 extra columns cost
+                               // the callers 29 spilled registers (0 without) and k_kdec_a/b their third wavefront; not the default
+#endif
 #ifndef ZKP_PREP_PS
 #define ZKP_PREP_PS 0   // product-scanning multiply in the by-value routines: measured +0.3 % time on the 2^20 pass (at two waves
                         // per SIMD the one-column dependency chains are not covered); the accumulator form stays
@@ -720,6 +725,14 @@ __device__ __attribute__((noinline)) Fp28 c_sqr(Fp28 mine, int c) {
     }
 #if ZKP_PREP_PS
     mont_mul_ps<false>(r.l, x, y, x, y);
+#elif ZKP_PREP_KARATSUBA
+    Acc acc;
+    AccMid mid;
+    acc_zero(acc);
+    mid_zero(mid);
+    acc_mul_k(acc, mid, x, y);
+    acc_fold(acc, mid);
+    acc_reduce(r.l, acc);
 #else
     Acc acc;
     acc_zero(acc);
@@ -752,6 +765,15 @@ __device__ __attribute__((noinline)) Fp28 c_mul_q(Fp28 ma, int4 q0, int4 q1, int
     }
 #if ZKP_PREP_PS
     mont_mul_ps<true>(r.l, x1, mb.l, x2, bo.l);
+#elif ZKP_PREP_KARATSUBA
+    Acc acc;
+    AccMid mid;
+    acc_zero(acc);
+    mid_zero(mid);
+    acc_mul_k(acc, mid, x1, mb.l);
+    acc_mul_k(acc, mid, x2, bo.l);
+    acc_fold(acc, mid);
+    acc_reduce(r.l, acc);
 #else
     Acc acc;
     acc_zero(acc);
@@ -767,6 +789,14 @@ __device__ __attribute__((noinline)) Fp28 f_mul_q(Fp28 a, int4 q0, int4 q1, int4
     fp28_unpack(b, q0, q1, q2, q3);
 #if ZKP_PREP_PS
     mont_mul_ps<false>(r.l, a.l, b.l, a.l, b.l);
+#elif ZKP_PREP_KARATSUBA
+    Acc acc;
+    AccMid mid;
+    acc_zero(acc);
+    mid_zero(mid);
+    acc_mul_k(acc, mid, a.l, b.l);
+    acc_fold(acc, mid);
+    acc_reduce(r.l, acc);
 #else
     fp28_mul(r, a, b);
 #endif
