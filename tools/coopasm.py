@@ -387,6 +387,151 @@ def write_fp2mul(f, vb=6):
     return g
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# k_ksq: one compressed squaring per loop iteration.  The block continues the Fp2 product above with everything that
+# follows it in the iteration except the rare snapshot store and the operand forms of the next product (C++):
+#   * the parked copy of the lane's old coefficient is requested behind the last product block (into the dead Y registers);
+#   * A lanes multiply X by -Y (the C++ forms negate Y for free), so their product arrives as -A: with -A the A-lane
+#     combination -t = 2 B_r - A_r - B_i (and its imaginary twin) is one DPP subtraction / addition and one v_lshl_add_u32 per
+#     limb, multiplier -3 in the carry chain; B lanes leave the doubling of their combination to the multiplier (6 instead
+#     of 3) and lane 3 needs no combination at all.  (A negated fetch of B would do the same without touching the forms, but
+#     v_subrev_u32_dpp does not permute its subtrahend on gfx950 - tools/dbg/dpp_probe.hip - and v_sub_u32_dpp negates the
+#     wrong operand.)
+#   * the two carry chains (3 t + 2 sgn x - q p, exact, balanced limbs) are three v_mad_i64_i32 + bfe + 64-bit add + shift
+#     per limb, interleaved; their results ARE the next product's X registers;
+#   * the new coefficient is parked from those registers (seven ds_write_b128: re0..re13, im0..im13 are 28 consecutive
+#     registers) and the pair partner's coefficient lands in the Y registers by DPP.
+# Same integers as sq_combine / the C++ combinations of zkp_coop.hip (tools/coopgen.py emu_ksq is the model).
+P_BLS = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+VRED_C, VRED_SHIFT_IN, VRED_SHIFT_OUT = 80647, 9, 24      # zkp_coop_prog.inc (asserted by write_inc)
+
+
+def p_balanced():
+    out, c = [], 0
+    for i in range(NL):
+        v = ((P_BLS >> (28 * i)) & 0xfffffff) + c
+        c = 0
+        if i < NL - 1 and v >= 1 << 27:
+            v -= 1 << 28
+            c = 1
+        out.append(v)
+    return out
+
+
+def generate_ksq(vb=6):
+    g = Fp2Mul(vb)
+    g.sEX, g.sMA, g.sM1, g.sM3, g.sPB = 38, 40, 42, 44, 46
+    g.send = g.sPB + NL
+    XR, XI, YR, YI, S, D = g.XR, g.XI, g.YR, g.YI, g.S, g.D
+    vaddr, mul, sgn2, nq_r, nq_i = D + 6, D + 8, D + 10, D + 11, D + 12
+    acc0 = g.ACC[0]
+    T1, T2, U, W = acc0, acc0 + 14, acc0 + 28, acc0 + 42           # 56 of the 78 accumulator registers
+    c_r, c_i, u_r, u_i, k27 = acc0 + 56, acc0 + 58, acc0 + 60, acc0 + 62, acc0 + 64
+    assert k27 + 2 <= g.vend and all(x % 2 == 0 for x in (c_r, c_i, u_r, u_i, k27))
+    QP = "quad_perm:[%s] row_mask:0xf bank_mask:0xf"
+    g.e("s_mov_b64 s[%d:%d], exec" % (g.sEX, g.sEX + 1))
+    # ---- the product (generate_fp2mul) with the old coefficient requested behind its last product block
+    kterm(g, XR, YI, True)
+    kterm(g, XI, YR, False)
+    tail(g, S)
+    for i in range(NL):
+        g.e("v_sub_u32 v%d, 0, v%d" % (XI + i, XI + i))
+    kterm(g, XR, YR, True)
+    kterm(g, XI, YI, False)
+    g.e("v_mbcnt_lo_u32_b32 v%d, -1, 0" % vaddr)
+    g.e("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (vaddr, vaddr))
+    g.e("v_lshlrev_b32 v%d, 4, v%d" % (vaddr, vaddr))
+    for k in range(7):
+        g.e("ds_read_b128 v[%d:%d], v%d offset:%d" % (YR + 4 * k, YR + 4 * k + 3, vaddr, 1024 * k))
+    tail(g, XR)
+    # ---- scalar constants: lane-role masks, the balanced limbs of p
+    for (sr, m) in ((g.sMA, 0x55555555), (g.sM1, 0x22222222)):
+        g.e("s_mov_b32 s%d, 0x%x" % (sr, m))
+        g.e("s_mov_b32 s%d, 0x%x" % (sr + 1, m))
+    for i, v in enumerate(p_balanced()):
+        g.e("s_mov_b32 s%d, 0x%x" % (g.sPB + i, v & 0xffffffff))
+    g.e("v_mov_b32 v%d, 6" % mul)
+    g.e("v_mov_b32 v%d, 2" % sgn2)
+    g.e("v_mov_b32 v%d, 0x8000000" % k27)
+    g.e("v_mov_b32 v%d, 0" % (k27 + 1))
+    # ---- B of the other pair (all lanes; a DPP read needs two wait states behind the write of its source)
+    g.e("s_nop 1")
+    for i in range(NL):
+        g.e(("v_mov_b32_dpp v%d, v%d " + QP) % (T1 + i, XR + i, "3,3,1,1"))
+    for i in range(NL):
+        g.e(("v_mov_b32_dpp v%d, v%d " + QP) % (T2 + i, S + i, "3,3,1,1"))
+    # ---- A lanes: -t = (2 B_r - A_r - B_i) + (2 B_i - A_i + B_r) u, -A from the other pair's even lane (an A lane: enabled)
+    g.e("s_mov_b64 exec, s[%d:%d]" % (g.sMA, g.sMA + 1))
+    for i in range(NL):
+        g.e(("v_sub_u32_dpp v%d, v%d, v%d " + QP) % (U + i, XR + i, T2 + i, "2,2,0,0"))
+        g.e(("v_add_u32_dpp v%d, v%d, v%d " + QP) % (W + i, S + i, T1 + i, "2,2,0,0"))
+    for i in range(NL):
+        g.e("v_lshl_add_u32 v%d, v%d, 1, v%d" % (T1 + i, T1 + i, U + i))
+        g.e("v_lshl_add_u32 v%d, v%d, 1, v%d" % (T2 + i, T2 + i, W + i))
+    g.e("v_mov_b32 v%d, -3" % mul)
+    g.e("v_mov_b32 v%d, -2" % sgn2)
+    # ---- lane 1: t/2 = (B_r - B_i) + (B_r + B_i) u;  lane 3: t/2 = B as it stands;  multiplier 6
+    g.e("s_mov_b64 exec, s[%d:%d]" % (g.sM1, g.sM1 + 1))
+    for i in range(NL):
+        g.e("v_sub_u32 v%d, v%d, v%d" % (U + i, T1 + i, T2 + i))
+        g.e("v_add_u32 v%d, v%d, v%d" % (T2 + i, T1 + i, T2 + i))
+    for i in range(NL):
+        g.e("v_mov_b32 v%d, v%d" % (T1 + i, U + i))
+    g.e("s_mov_b64 exec, s[%d:%d]" % (g.sEX, g.sEX + 1))
+    g.e("s_waitcnt lgkmcnt(0)")          # the old coefficient: re in the YR registers, im in the YI registers
+    # ---- q = round((mult t13 + sgn2 x13) / p_top) per coefficient (zkp_coop.hip sq_combine), negated
+    for (nq, T, X) in ((nq_r, T1, YR), (nq_i, T2, YI)):
+        g.e("v_mul_i32_i24 v%d, v%d, v%d" % (nq, T + NL - 1, mul))
+        g.e("v_mad_i32_i24 v%d, v%d, v%d, v%d" % (nq, X + NL - 1, sgn2, nq))
+        g.e("v_ashrrev_i32 v%d, %d, v%d" % (nq, VRED_SHIFT_IN, nq))
+        g.e("v_mul_i32_i24 v%d, 0x%x, v%d" % (nq, VRED_C, nq))
+        g.e("v_add_u32 v%d, 0x%x, v%d" % (nq, 1 << (VRED_SHIFT_OUT - 1), nq))
+        g.e("v_ashrrev_i32 v%d, %d, v%d" % (nq, VRED_SHIFT_OUT, nq))
+        g.e("v_sub_u32 v%d, 0, v%d" % (nq, nq))
+    # ---- the two carry chains, interleaved; results: the new coefficient in XR / XI
+    for i in range(NL):
+        for (c, u, T, X, nq, OUT) in ((c_r, u_r, T1, YR, nq_r, XR), (c_i, u_i, T2, YI, nq_i, XI)):
+            g.mad(c, vreg(T + i), vreg(mul), None if i == 0 else c)
+            g.mad(c, vreg(X + i), vreg(sgn2), c)
+            g.mad(c, vreg(nq), "s%d" % (g.sPB + i), c)
+            if i < NL - 1:
+                g.e("v_bfe_i32 v%d, v%d, 0, 28" % (OUT + i, c))
+                g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (u, u + 1, c, c + 1, k27, k27 + 1))
+                g.e("v_ashrrev_i64 v[%d:%d], 28, v[%d:%d]" % (c, c + 1, u, u + 1))
+            else:
+                g.e("v_mov_b32 v%d, v%d" % (OUT + i, c))
+    # ---- park the new coefficient (the "2 x" of the next squaring), fetch the pair partner's into the Y registers
+    for k in range(7):
+        g.e("ds_write_b128 v%d, v[%d:%d] offset:%d" % (vaddr, XR + 4 * k, XR + 4 * k + 3, 1024 * k))
+    g.e("s_nop 1")
+    for i in range(NL):
+        g.e(("v_mov_b32_dpp v%d, v%d " + QP) % (YR + i, XR + i, "1,0,3,2"))
+    for i in range(NL):
+        g.e(("v_mov_b32_dpp v%d, v%d " + QP) % (YI + i, XI + i, "1,0,3,2"))
+    g.e("s_waitcnt lgkmcnt(0)")
+    return g
+
+
+def write_ksq(f, vb=6):
+    g = generate_ksq(vb)
+    n = sum(1 for l in g.lines if not l.endswith(":"))
+    f.write("// One compressed squaring of k_ksq behind the operand forms: %d instructions; VGPRs v%d..v%d, SGPRs s%d..s%d.\n"
+            % (n, g.vb, g.vend - 1, g.sb, g.send - 1))
+    f.write("#define ZKP_KSQ_BODY_ASM \\\n")
+    for l in g.lines:
+        f.write('    "%s\\n\\t" \\\n' % l)
+    f.write('    ""\n')
+    f.write("// in: the product's factors X = xr + xi u and Y = yr + yi u (B lanes) or -Y (A lanes); out: the lane's new coefficient (xr, xi), its pair partner's (yr, yi)\n")
+    f.write("#define ZKP_KSQ_BODY_IO(xr, xi, yr, yi) " + ", ".join(
+        ", ".join('"+{v%d}"((%s)[%d])' % (base + i, nm, i) for i in range(NL))
+        for nm, base in (("xr", g.XR), ("xi", g.XI), ("yr", g.YR), ("yi", g.YI))) + "\n")
+    f.write("#define ZKP_KSQ_BODY_CLOBBERS " + ", ".join('"v%d"' % v for v in range(g.S, g.vend)) + ", "
+            + ", ".join('"s%d"' % x for x in range(g.sb, g.send)) + ', "scc", "memory"\n')
+    f.write("#define ZKP_KSQ_BODY_P_BAL " + ", ".join(str(v) for v in p_balanced()) + "\n")
+    f.write("#define ZKP_KSQ_BODY_VRED %d, %d, %d\n" % (VRED_C, VRED_SHIFT_IN, VRED_SHIFT_OUT))
+    return g
+
+
 def write_inc(path, vb=8):
     g, out = generate(vb)
     outs = list(range(out, out + NL))
@@ -403,7 +548,7 @@ def write_inc(path, vb=8):
         f.write('    ""\n')
         f.write("#define ZKP_MULACC_OUTS(r) " + ", ".join('"={v%d}"((r)[%d])' % (outs[i], i) for i in range(NL)) + "\n")
         f.write("#define ZKP_MULACC_CLOBBERS " + ", ".join('"v%d"' % v for v in vclob) + ", " + ", ".join('"s%d"' % s for s in sclob) + ', "scc", "memory"\n')
-        write_fp2mul(f)
+        write_ksq(f)
     return g
 
 

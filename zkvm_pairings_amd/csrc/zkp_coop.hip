@@ -514,18 +514,18 @@ __device__ __forceinline__ void park_st(int4* xch, int lane, const int32_t* re, 
     xch[0 * 64 + lane] = make_int4(re[0], re[1], re[2], re[3]);
     xch[1 * 64 + lane] = make_int4(re[4], re[5], re[6], re[7]);
     xch[2 * 64 + lane] = make_int4(re[8], re[9], re[10], re[11]);
-    xch[3 * 64 + lane] = make_int4(re[12], re[13], im[12], im[13]);
-    xch[4 * 64 + lane] = make_int4(im[0], im[1], im[2], im[3]);
-    xch[5 * 64 + lane] = make_int4(im[4], im[5], im[6], im[7]);
-    xch[6 * 64 + lane] = make_int4(im[8], im[9], im[10], im[11]);
+    xch[3 * 64 + lane] = make_int4(re[12], re[13], im[0], im[1]);     // re0..re13, im0..im13 as seven quads: the asm body of k_ksq
+    xch[4 * 64 + lane] = make_int4(im[2], im[3], im[4], im[5]);       // parks them straight from 28 consecutive registers
+    xch[5 * 64 + lane] = make_int4(im[6], im[7], im[8], im[9]);
+    xch[6 * 64 + lane] = make_int4(im[10], im[11], im[12], im[13]);
 }
 __device__ __forceinline__ void park_ld(int32_t* re, int32_t* im, const int4* xch, int lane) {
     const int4 r0 = xch[0 * 64 + lane], r1 = xch[1 * 64 + lane], r2 = xch[2 * 64 + lane], r3 = xch[3 * 64 + lane];
     const int4 i0 = xch[4 * 64 + lane], i1 = xch[5 * 64 + lane], i2 = xch[6 * 64 + lane];
     re[0] = r0.x; re[1] = r0.y; re[2] = r0.z; re[3] = r0.w; re[4] = r1.x; re[5] = r1.y; re[6] = r1.z; re[7] = r1.w;
-    re[8] = r2.x; re[9] = r2.y; re[10] = r2.z; re[11] = r2.w; re[12] = r3.x; re[13] = r3.y; im[12] = r3.z; im[13] = r3.w;
-    im[0] = i0.x; im[1] = i0.y; im[2] = i0.z; im[3] = i0.w; im[4] = i1.x; im[5] = i1.y; im[6] = i1.z; im[7] = i1.w;
-    im[8] = i2.x; im[9] = i2.y; im[10] = i2.z; im[11] = i2.w;
+    re[8] = r2.x; re[9] = r2.y; re[10] = r2.z; re[11] = r2.w; re[12] = r3.x; re[13] = r3.y; im[0] = r3.z; im[1] = r3.w;
+    im[2] = i0.x; im[3] = i0.y; im[4] = i0.z; im[5] = i0.w; im[6] = i1.x; im[7] = i1.y; im[8] = i1.z; im[9] = i1.w;
+    im[10] = i2.x; im[11] = i2.y; im[12] = i2.z; im[13] = i2.w;
 }
 // out = 3 t + 2 sgn x - q p (sgn = -1 where neg is all ones) with q = round(value / p) taken from the top limbs, as ONE
 // exact carry chain (balanced limbs, the top limb keeps the rest); |result| < 0.51 p.  (The chain stays in 64 bits: t is a
@@ -554,6 +554,22 @@ __device__ __forceinline__ void sq_combine(int32_t* out, const int32_t* t, const
 }
 #define ZKP_QUAD(x, ctrl) __builtin_amdgcn_update_dpp(0, (x), (ctrl), 0xf, 0xf, false)
 
+// operand forms of a lane's next product, in place: in (x, y) = (the lane's coefficient, its pair partner's).  B lanes: u v =
+// mine * partner as they stand.  A lanes: X = u + v and MINUS Y = -(u + xi v), u + xi v = (u0 + v0 - v1) + (u1 + v1 + v0) u with
+// v = mine on lane 0, the partner on lane 2 - the asm body wants the A product negated, and here the sign is one operand swap
+__device__ __forceinline__ void ksq_forms(int32_t* xr, int32_t* xi, int32_t* yr, int32_t* yi, bool a_lane, bool v_mine) {
+    if (a_lane) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int32_t tr = xr[i] + yr[i], ti = xi[i] + yi[i];
+            const int32_t vr = v_mine ? xr[i] : yr[i], vi = v_mine ? xi[i] : yi[i];
+            xr[i] = tr;
+            xi[i] = ti;
+            yr[i] = vi - tr;
+            yi[i] = -ti - vr;
+        }
+    }
+}
 #ifndef ZKP_KSQ_ASM
 #define ZKP_KSQ_ASM ZKP_COOP_ASM   // the Fp2 product of k_ksq as the interpreter's Karatsuba term + tail on register operands (tools/coopasm.py:
                                    // 980 multiply-adds instead of the 1,204 of two product-scanning multiplies); 0: mont_mul_ps, the A/B baseline
@@ -570,7 +586,7 @@ __device__ __forceinline__ void sq_combine(int32_t* out, const int32_t* t, const
 // elem_snap on, laid out like an Fp12 value whose z0, z1 positions are left for k_kdec_b to fill.
 __global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_in, uint32_t elem_snap,
                                                            uint32_t nsq, uint64_t snap_mask) {
-    __shared__ int4 parked[7 * 64];
+    extern __shared__ int4 parked[];               // 7 x 64 quads, at LDS address 0 (the asm body addresses it by lane number)
     const int lane = threadIdx.x;
     const int r = lane & 3;                        // 0: A23, 1: B23, 2: A45, 3: B45
     const bool b_lane = r & 1;
@@ -606,32 +622,78 @@ __global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t
         rec_load(u1, rec(elem_in + 2 * tu + 1));
         rec_load(v0, rec(elem_in + 2 * tv));
         rec_load(v1, rec(elem_in + 2 * tv + 1));
+#if ZKP_KSQ_ASM
+        const Fp28 &m0 = mine_is_v ? v0 : u0, &m1 = mine_is_v ? v1 : u1, &o0 = mine_is_v ? u0 : v0, &o1 = mine_is_v ? u1 : v1;
+        park_st(parked, lane, m0.l, m1.l);
+#pragma unroll
+        for (int i = 0; i < NL; i++) { xr[i] = m0.l[i]; xi[i] = m1.l[i]; yr[i] = o0.l[i]; yi[i] = o1.l[i]; }
+        ksq_forms(xr, xi, yr, yi, !b_lane, r == 0);
+#else
         if (mine_is_v) advance(v0.l, v1.l, u0.l, u1.l); else advance(u0.l, u1.l, v0.l, v1.l);
+#endif
     }
     uint32_t snap = elem_snap;
+#if ZKP_KSQ_ASM
+    // One inline-asm block per squaring (tools/coopasm.py generate_ksq): the Fp2 product, the other pair's products by DPP, the
+    // lane-role combinations, both carry chains, the parking of the new coefficient and the pair partner's coefficient by DPP.
+    // In: X = xr + xi u, Y = yr + yi u.  Out: the lane's new coefficient in (xr, xi), its partner's in (yr, yi) - the
+    // snapshot store and the next product's operand forms stay here.
+    static_assert(NL == 14, "the generated block is for 14 limbs");
+    {
+        constexpr int32_t PB[NL] = {ZKP_KSQ_BODY_P_BAL}, KB[NL] = {ZKP_COOP_P_BAL};
+        constexpr int VR[3] = {ZKP_KSQ_BODY_VRED};
+        static_assert(VR[0] == ZKP_COOP_VRED_C && VR[1] == ZKP_COOP_VRED_SHIFT_IN && VR[2] == ZKP_COOP_VRED_SHIFT_OUT, "regenerate zkp_coop_mulacc.inc");
+        static_assert(PB[0] == KB[0] && PB[1] == KB[1] && PB[5] == KB[5] && PB[12] == KB[12] && PB[13] == KB[13], "regenerate zkp_coop_mulacc.inc");
+    }
+#pragma unroll 1
+    for (uint32_t it = 0; it < nsq; it++) {
+        {
+            constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};
+            asm volatile(ZKP_KSQ_BODY_ASM
+                         : ZKP_KSQ_BODY_IO(xr, xi, yr, yi)
+                         : [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]), [p6] "s"(PL[6]),
+                           [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]), [p12] "s"(PL[12]),
+                           [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)
+                         : ZKP_KSQ_BODY_CLOBBERS);
+        }
+        // per-lane values re-derived from an opaque copy of the lane number: kept in registers across the block (which owns 162 of
+        // the 168 VGPRs) they would be spilled and reloaded in every squaring
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+        const bool a_lane = !(l_ & 1), v_mine = (l_ & 3) == 0;     // lane 0 holds (v, u) = (mine, partner), lane 2 (u, v)
+        if (it < 64 && ((snap_mask >> it) & 1)) {      // wave-uniform (a 64-bit shift by 64 or more is undefined)
+            const uint32_t chk_ = blockIdx.x * KS_CHECKS + (l_ >> 2);
+            int4* const st_ = state + (size_t)(chk_ < n_checks ? chk_ : n_checks - 1) * 4;
+            auto rec_ = [&](uint32_t e) -> int4* { return st_ + (size_t)e * nc * 4; };
+            const int tu_ = (l_ & 2) ? 1 : 3, tv_ = (l_ & 2) ? 5 : 2;
+            if (chk_ < n_checks && a_lane) {
+                Fp28 o;
+#pragma unroll
+                for (int i = 0; i < NL; i++) o.l[i] = xr[i];
+                rec_store(rec_(snap + 2 * (v_mine ? tv_ : tu_)), o);
+#pragma unroll
+                for (int i = 0; i < NL; i++) o.l[i] = xi[i];
+                rec_store(rec_(snap + 2 * (v_mine ? tv_ : tu_) + 1), o);
+#pragma unroll
+                for (int i = 0; i < NL; i++) o.l[i] = yr[i];
+                rec_store(rec_(snap + 2 * (v_mine ? tu_ : tv_)), o);
+#pragma unroll
+                for (int i = 0; i < NL; i++) o.l[i] = yi[i];
+                rec_store(rec_(snap + 2 * (v_mine ? tu_ : tv_) + 1), o);
+            }
+            snap += 12;
+        }
+        ksq_forms(xr, xi, yr, yi, a_lane, v_mine);
+    }
+#else
 #pragma unroll 1
     for (uint32_t it = 0; it < nsq; it++) {
         int32_t sre[NL], sim[NL];
         // X Y = (X0 Y0 - X1 Y1) + (X0 Y1 + X1 Y0) u, one reduction per coefficient
-#if ZKP_KSQ_ASM
-        {
-            constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};
-            asm volatile(ZKP_FP2MUL_ASM
-                         : ZKP_FP2MUL_OUTS(xr, xi, sim)
-                         : ZKP_FP2MUL_INS(yr, yi),
-                           [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]), [p6] "s"(PL[6]),
-                           [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]), [p12] "s"(PL[12]),
-                           [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)
-                         : ZKP_FP2MUL_CLOBBERS);
-#pragma unroll
-            for (int i = 0; i < NL; i++) sre[i] = xr[i];     // the block leaves the real part in xr's registers
-        }
-#else
         mont_mul_ps<true>(sim, xr, yi, xi, yr);
 #pragma unroll
         for (int i = 0; i < NL; i++) xi[i] = -xi[i];
         mont_mul_ps<true>(sre, xr, yr, xi, yi);
-#endif
         // the other pair's products: A from its even lane, B from its odd lane.  The DPP reads stay outside the lane-role
         // branches: a DPP read from a lane that the branch has switched off returns nothing.
         int32_t tr[NL], ti[NL];
@@ -665,15 +727,6 @@ __global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t
 #pragma unroll
         for (int i = 0; i < NL; i++) { pr[i] = ZKP_QUAD(sre[i], 0xB1); pi[i] = ZKP_QUAD(sim[i], 0xB1); }   // quad_perm [1,0,3,2]
         if (it < 64 && ((snap_mask >> it) & 1)) {      // wave-uniform (a 64-bit shift by 64 or more is undefined)
-#if ZKP_KSQ_ASM
-            // the record pointer is re-derived here from an opaque copy of the lane number: kept in registers across the asm block
-            // (which owns 162 of the 168 VGPRs) it would be spilled and reloaded in every squaring, for six uses per run
-            int l_ = lane;
-            asm volatile("" : "+v"(l_));
-            const uint32_t chk_ = blockIdx.x * KS_CHECKS + (l_ >> 2);
-            int4* const st_ = state + (size_t)(chk_ < n_checks ? chk_ : n_checks - 1) * 4;
-            auto rec = [&](uint32_t e) -> int4* { return st_ + (size_t)e * nc * 4; };
-#endif
             if (active && !b_lane) {      // lane 0 holds (v, u) = (mine, partner), lane 2 (u, v)
                 Fp28 o;
 #pragma unroll
@@ -693,6 +746,7 @@ __global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t
         }
         advance(sre, sim, pr, pi);
     }
+#endif
 }
 
 // ---- two lanes per pair: lane parity c selects the Fp2 coefficient a value's lane holds ------------------
@@ -1991,7 +2045,7 @@ static hipError_t run_ksq(hipStream_t s, int4* state, uint32_t n_checks, uint32_
                           uint64_t snap_mask) {
     if (!n_checks || !nsq) return hipSuccess;
     if (snap_mask && nsq > 64) return hipErrorInvalidValue;   // snapshot bits exist for the first 64 squarings only
-    hipLaunchKernelGGL(k_ksq, dim3((n_checks + KS_CHECKS - 1) / KS_CHECKS), dim3(64), 0, s, state, n_checks, nc, elem_in, elem_snap, nsq, snap_mask);
+    hipLaunchKernelGGL(k_ksq, dim3((n_checks + KS_CHECKS - 1) / KS_CHECKS), dim3(64), 7 * 64 * sizeof(int4), s, state, n_checks, nc, elem_in, elem_snap, nsq, snap_mask);
     return hipGetLastError();
 }
 
