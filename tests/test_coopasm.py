@@ -103,3 +103,123 @@ def test_ksq_body_equals_the_model_of_a_compressed_squaring():
                     state[i] = st[12 + i]
             mine = [want[r] for r in range(4)]
             other = [want[r ^ 1] for r in range(4)]
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the interpreter's MULACC block: every MULACC step of a few step programs, on the lanes of one check, against the columns
+# tools/coopgen.py's emulator accumulates and reduces for that step
+def _resolved_rows(st, S, SC):
+    """zkp_coop.hip coop_resolve_table for one step and the lanes of group 0: per term a row of (A1, B1, A2 | B2 << 16) byte
+    addresses, then the row of flag words"""
+    SG = S + ((4 - S % 8) + 8) % 8
+    addr = lambda slot: 16 * ((0 if slot & 64 else SC) + (slot & 63))
+    T = st["T"]
+    rows = [[(0, 0, 0)] * 12 for _ in range(T + 1)]
+    for lig in range(12):
+        ln = st["lanes"][lig] if lig < len(st["lanes"]) else None
+        f1 = f2 = 0
+        for t in range(T):
+            if ln is None or t >= len(ln["terms"]):
+                a1 = a2 = b1 = b2 = cg.ZERO
+                asub = bsub = neg = da = 0
+            else:
+                a1, a2, asub, b1, b2, bsub, neg, da = ln["terms"][t]
+            rows[t][lig] = (addr(a1), addr(b1), addr(a2) | (addr(b2) << 16))
+            f1 |= (int(neg) << t) | (int(da) << (12 + t))
+            f2 |= (int(asub) << t) | (int(bsub) << (12 + t))
+        rows[T][lig] = (f1, f2, 0)
+    return rows, SG
+
+
+def _run_mulacc_block(g, out, st, slots, S, SC):
+    """execute the generated block for one MULACC step on 12 lanes; slots: slot number -> 14 limbs (constants included)"""
+    rows, SG = _resolved_rows(st, S, SC)
+    PS = SC + 5 * SG
+    T = st["T"]
+    hdr1 = hdr3 = 0
+    for t in range(T):
+        ts = [ln["terms"][t] for ln in st["lanes"] if t < len(ln["terms"])]
+        if all(x[1] == cg.ZERO and not x[2] for x in ts):
+            hdr3 |= 1 << t
+        if all(x[4] == cg.ZERO and not x[5] for x in ts):
+            hdr3 |= 1 << (12 + t)
+        if not any(x[6] for x in ts):
+            hdr1 |= 1 << (4 + t)
+        if any(x[7] for x in ts):
+            hdr1 |= 1 << (16 + t)
+    subst = _subst()
+    subst.update({"rt": "s[100:101]", "T": "s102", "h1": "s103", "h3": "s104", "lane16": "v1", "ps1": PS * 16, "ps2": PS * 32, "ps3": PS * 48, "row": 1024})
+    emu = asmemu.Emu(lanes=12, subst=subst)
+    base = 0x40000
+    emu.s[100], emu.s[101], emu.s[102], emu.s[103], emu.s[104] = base, 0, T, hdr1, hdr3
+    emu.v[1] = [16 * lane for lane in range(12)]
+    for r, row in enumerate(rows):
+        for lane, ent in enumerate(row):
+            for k in range(4):
+                emu.mem[base + 1024 * r + 16 * lane + 4 * k] = (ent[k] if k < 3 else 0) & asmemu.M32
+    for extra in range(2):       # the block reads one row past the flag row's predecessor ahead of itself (the table is padded)
+        for lane in range(12):
+            for k in range(4):
+                emu.mem.setdefault(base + 1024 * (len(rows) + extra) + 16 * lane + 4 * k, 0)
+    for slot, limbs in slots.items():
+        idx = (0 if slot & 64 else SC) + (slot & 63)
+        for i in range(NL):
+            emu.lds[16 * idx + (i // 4) * PS * 16 + 4 * (i % 4)] = limbs[i] & asmemu.M32
+        for i in (14, 15):
+            emu.lds[16 * idx + 3 * PS * 16 + 4 * (i % 4)] = 0
+    emu.run(g.lines)
+    return [[asmemu.s32(emu.v[out + i][lane]) for i in range(NL)] for lane in range(12)], emu
+
+
+def _check_program(builder, S, SC, em, max_steps=None):
+    g, out = coopasm.generate()
+    done = 0
+    steps = builder.steps
+    pc, loop_start, loop_left = 0, None, 0
+    while pc < len(steps):
+        st = steps[pc]
+        if st["op"] == cg.OP_MULACC and (max_steps is None or done < max_steps):
+            got, emu = _run_mulacc_block(g, out, st, em.slot, S, SC)
+            for lig, ln in enumerate(st["lanes"]):
+                col = [0] * (2 * NL - 1)
+                for (a1, a2, asub, b1, b2, bsub, neg, da) in ln["terms"]:
+                    a, b = em.form(a1, a2, asub), em.form(b1, b2, bsub)
+                    a = [-x for x in a] if neg else a
+                    a = [2 * x for x in a] if da else a
+                    for i in range(NL):
+                        for j in range(NL):
+                            col[i + j] += a[i] * b[j]
+                assert got[lig] == cg.acc_reduce(col), (pc, lig)
+            done += 1
+        em.run([st]) if st["op"] not in (cg.OP_LOOP, cg.OP_ENDLOOP) else None
+        if st["op"] == cg.OP_LOOP:
+            loop_start, loop_left = pc + 1, min(st["n"], 2)      # two iterations of a loop are enough here
+        elif st["op"] == cg.OP_ENDLOOP:
+            loop_left -= 1
+            if loop_left > 0:
+                pc = loop_start
+                continue
+        pc += 1
+    return done
+
+
+def test_mulacc_block_equals_the_emulator_on_the_tower_programs():
+    """fp12_mul (T = 12, two-slot B operands), fp12_sqr (doubled A operands, negated terms), cyc_sqr (three terms; the epilogue is
+    compiled code behind the block), fp12_014: the block's 14 result limbs per lane are the emulator's reduced columns"""
+    rng = random.Random(5)
+    for op in ("fp12_mul", "fp12_sqr", "fp12_014", "cyc_sqr", "fp6_mul"):
+        b = cg.prog_tower(op)
+        wire = [rng.randrange(cg.P) for _ in range(12)]
+        wire2 = [rng.randrange(cg.P) for _ in range(12)]
+        em = cg.Emu(wire_in=wire, wire_in2=wire2)
+        assert _check_program(b, cg.LDS_SLOTS, cg.N_CONST, em) >= 1, op
+
+
+def test_mulacc_block_equals_the_emulator_on_miller_steps():
+    """the first steps of the Miller program of one pair (30-slot configuration, companion slots, loops): line products (T = 6)
+    and accumulator squarings (T = 7)"""
+    import bls12_381_model as m
+    lines = cg.model_lines([(m.G1_GEN, m.G2_GEN)])
+    b = cg.prog_miller(1, False)
+    em = cg.Emu(lines=lines)
+    assert _check_program(b, cg.LDS_WIDE_SLOTS, cg.LDS_WIDE_CONSTS, em, max_steps=6) == 6

@@ -39,6 +39,8 @@ class Emu:
         self.s = {}
         self.exec = (1 << lanes) - 1
         self.lds = {}               # byte address -> dword (addresses are multiples of 4)
+        self.mem = {}               # global memory: byte address -> dword
+        self.scc = 0
         self.subst = dict(subst or {})
         self.strict = strict
         self.count = {}
@@ -91,12 +93,27 @@ class Emu:
         self.v.setdefault(int(m.group(1)), [None] * self.n)[lane] = val & M32
 
     # ---- execution
-    def run(self, lines):
-        for raw in lines:
-            line = self._sub(raw).strip()
-            if not line or line.endswith(":"):
+    def run(self, lines, max_steps=10_000_000):
+        prog = [self._sub(l).strip() for l in lines]
+        prog = [l for l in prog if l]
+        labels = {l[:-1]: i for i, l in enumerate(prog) if l.endswith(":")}
+        pc, n = 0, 0
+        while pc < len(prog):
+            line = prog[pc]
+            pc += 1
+            if line.endswith(":"):
+                continue
+            n += 1
+            assert n < max_steps, "runaway loop"
+            op = line.split(None, 1)[0]
+            if op in ("s_branch", "s_cbranch_scc0", "s_cbranch_scc1"):
+                self.count[op] = self.count.get(op, 0) + 1
+                target = line.split(None, 1)[1].strip()
+                if op == "s_branch" or (op == "s_cbranch_scc1") == bool(self.scc):
+                    pc = labels[target]
                 continue
             self.step(line)
+        return self
 
     def step(self, line):
         mods = {}
@@ -123,7 +140,7 @@ class Emu:
         fn = getattr(self, "op_" + op, None)
         if fn is None:
             raise NotImplementedError(op)
-        if op.startswith("s_") or op.startswith("ds_"):
+        if op.startswith("s_") or op.startswith("ds_") or op.startswith("global_"):
             fn(args, mods)
             return
         for lane in range(self.n):
@@ -171,6 +188,83 @@ class Emu:
         val = ((1 << 64) - 1 if self.exec == (1 << self.n) - 1 else self.exec) if a[1] == "exec" else self.rd(a[1], 0)
         self.s[lo], self.s[lo + 1] = val & M32, (val >> 32) & M32
 
+    def _sr(self, x):
+        x = x.strip()
+        return self.s[int(x[1:])] if re.fullmatch(r"s\d+", x) else int(x, 0) & M32
+
+    def _sw(self, x, v):
+        self.s[int(x.strip()[1:])] = v & M32
+
+    def op_s_lshr_b32(self, a, m):
+        self._sw(a[0], self._sr(a[1]) >> (self._sr(a[2]) & 31))
+        self.scc = int(self._sr(a[0]) != 0)
+
+    def op_s_lshl_b32(self, a, m):
+        self._sw(a[0], self._sr(a[1]) << (self._sr(a[2]) & 31))
+        self.scc = int(self._sr(a[0]) != 0)
+
+    def op_s_and_b32(self, a, m):
+        self._sw(a[0], self._sr(a[1]) & self._sr(a[2]))
+        self.scc = int(self._sr(a[0]) != 0)
+
+    def op_s_add_u32(self, a, m):
+        v = self._sr(a[1]) + self._sr(a[2])
+        self._sw(a[0], v)
+        self.scc = v >> 32
+
+    def op_s_addc_u32(self, a, m):
+        v = self._sr(a[1]) + self._sr(a[2]) + self.scc
+        self._sw(a[0], v)
+        self.scc = v >> 32
+
+    def op_s_mul_i32(self, a, m):
+        self._sw(a[0], s32(self._sr(a[1])) * s32(self._sr(a[2])))
+
+    def op_s_cmp_ge_u32(self, a, m):
+        self.scc = int(self._sr(a[0]) >= self._sr(a[1]))
+
+    def op_s_cmp_lt_u32(self, a, m):
+        self.scc = int(self._sr(a[0]) < self._sr(a[1]))
+
+    def op_s_cmp_eq_u32(self, a, m):
+        self.scc = int(self._sr(a[0]) == self._sr(a[1]))
+
+    def op_s_bitcmp1_b32(self, a, m):
+        self.scc = (self._sr(a[0]) >> (self._sr(a[1]) & 31)) & 1
+
+    def _gload(self, a, m, n):
+        base = self.rd(a[2], 0) if a[2].strip() != "off" else 0
+        for lane in range(self.n):
+            if (self.exec >> lane) & 1:
+                addr = base + self.rd(a[1], lane) + m.get("offset", 0)
+                assert addr % 4 == 0
+                for k in range(n):
+                    if addr + 4 * k not in self.mem:
+                        raise RuntimeError("global read of unwritten address 0x%x" % (addr + 4 * k))
+                    self.v.setdefault(self._vbase(a[0]) + k, [None] * self.n)[lane] = self.mem[addr + 4 * k]
+
+    @staticmethod
+    def _vbase(op):
+        mm = re.fullmatch(r"v\[(\d+):(\d+)\]", op.strip())
+        return int(mm.group(1)) if mm else int(op.strip()[1:])
+
+    def op_global_load_dwordx3(self, a, m):
+        self._gload(a, m, 3)
+
+    def op_global_load_dwordx2(self, a, m):
+        self._gload(a, m, 2)
+
+    def op_ds_read_b64(self, a, m):
+        off = m.get("offset", 0)
+        for lane in range(self.n):
+            if (self.exec >> lane) & 1:
+                addr = self.rd(a[1], lane) + off
+                assert addr % 8 == 0
+                for k in range(2):
+                    if addr + 4 * k not in self.lds:
+                        raise RuntimeError("LDS read of unwritten address %d" % (addr + 4 * k))
+                self.wr(a[0], lane, sum(self.lds[addr + 4 * k] << (32 * k) for k in range(2)), 2)
+
     def op_ds_read_b128(self, a, m):
         off = m.get("offset", 0)
         for lane in range(self.n):
@@ -210,6 +304,13 @@ class Emu:
 
     def op_v_xad_u32(self, a, l, sl):
         self.wr(a[0], l, (self.rd(a[1], l) ^ self.rd(a[2], l)) + self.rd(a[3], l))
+
+    def op_v_lshrrev_b32(self, a, l, sl):
+        self.wr(a[0], l, self.rd(a[2], l) >> (self.rd(a[1], l) & 31))
+
+    def op_v_bfe_u32(self, a, l, sl):
+        x, off, w = self.rd(a[1], l), self.rd(a[2], l) & 31, self.rd(a[3], l) & 31
+        self.wr(a[0], l, (x >> off) & ((1 << w) - 1))
 
     def op_v_lshlrev_b32(self, a, l, sl):
         self.wr(a[0], l, self.rd(a[2], l) << (self.rd(a[1], l) & 31))
