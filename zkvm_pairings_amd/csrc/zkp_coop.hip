@@ -509,6 +509,17 @@ __device__ __forceinline__ void rec_load(Fp28& x, const int4* src) {
 // of |x|); k_kdec_a / k_batch_inv / k_kdec_b recover z0, z1 of the six snapshots (one shared batched inversion), and the
 // step program multiplies them.  tools/coopgen.py emu_ksq / emu_kdec are the limb-exact models of these kernels.
 constexpr int KS_CHECKS = 16;
+#ifndef ZKP_KSQ_ASM
+#define ZKP_KSQ_ASM ZKP_COOP_ASM   // the Fp2 product of k_ksq as the interpreter's Karatsuba term + tail on register operands (tools/coopasm.py:
+                                   // 980 multiply-adds instead of the 1,204 of two product-scanning multiplies); 0: mont_mul_ps, the A/B baseline
+#endif
+#ifndef ZKP_KSQ_WAVES
+#if ZKP_KSQ_ASM
+#define ZKP_KSQ_WAVES 3            // the block pins 162 VGPRs (four operands, both results' homes, 78 accumulator registers)
+#else
+#define ZKP_KSQ_WAVES 4
+#endif
+#endif
 
 __device__ __forceinline__ void park_st(int4* xch, int lane, const int32_t* re, const int32_t* im) {
     xch[0 * 64 + lane] = make_int4(re[0], re[1], re[2], re[3]);
@@ -519,6 +530,7 @@ __device__ __forceinline__ void park_st(int4* xch, int lane, const int32_t* re, 
     xch[5 * 64 + lane] = make_int4(im[6], im[7], im[8], im[9]);
     xch[6 * 64 + lane] = make_int4(im[10], im[11], im[12], im[13]);
 }
+#if !ZKP_KSQ_ASM
 __device__ __forceinline__ void park_ld(int32_t* re, int32_t* im, const int4* xch, int lane) {
     const int4 r0 = xch[0 * 64 + lane], r1 = xch[1 * 64 + lane], r2 = xch[2 * 64 + lane], r3 = xch[3 * 64 + lane];
     const int4 i0 = xch[4 * 64 + lane], i1 = xch[5 * 64 + lane], i2 = xch[6 * 64 + lane];
@@ -553,10 +565,12 @@ __device__ __forceinline__ void sq_combine(int32_t* out, const int32_t* t, const
     }
 }
 #define ZKP_QUAD(x, ctrl) __builtin_amdgcn_update_dpp(0, (x), (ctrl), 0xf, 0xf, false)
+#endif
 
 // operand forms of a lane's next product, in place: in (x, y) = (the lane's coefficient, its pair partner's).  B lanes: u v =
 // mine * partner as they stand.  A lanes: X = u + v and MINUS Y = -(u + xi v), u + xi v = (u0 + v0 - v1) + (u1 + v1 + v0) u with
 // v = mine on lane 0, the partner on lane 2 - the asm body wants the A product negated, and here the sign is one operand swap
+#if ZKP_KSQ_ASM
 __device__ __forceinline__ void ksq_forms(int32_t* xr, int32_t* xi, int32_t* yr, int32_t* yi, bool a_lane, bool v_mine) {
     if (a_lane) {
 #pragma unroll
@@ -570,16 +584,6 @@ __device__ __forceinline__ void ksq_forms(int32_t* xr, int32_t* xi, int32_t* yr,
         }
     }
 }
-#ifndef ZKP_KSQ_ASM
-#define ZKP_KSQ_ASM ZKP_COOP_ASM   // the Fp2 product of k_ksq as the interpreter's Karatsuba term + tail on register operands (tools/coopasm.py:
-                                   // 980 multiply-adds instead of the 1,204 of two product-scanning multiplies); 0: mont_mul_ps, the A/B baseline
-#endif
-#ifndef ZKP_KSQ_WAVES
-#if ZKP_KSQ_ASM
-#define ZKP_KSQ_WAVES 3            // the block pins 162 VGPRs (four operands, both results' homes, 78 accumulator registers)
-#else
-#define ZKP_KSQ_WAVES 4
-#endif
 #endif
 // nsq compressed squarings of the Fp12 value in state elements [elem_in, elem_in + 12) (only z2..z5 are read); after
 // squaring number it + 1 where bit it of snap_mask is set, (z2..z5) go to the next snapshot area: 12 elements each from
@@ -601,6 +605,7 @@ __global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t
     // X, Y: the two factors of the lane's product.  `mine` is the lane's own coefficient of its pair (u, v) - v on lanes 0
     // and 3, u on lanes 1 and 2 - and `other` the pair partner's.  B lanes: u v = mine * other.  A lanes: (u + v)(u + xi v).
     int32_t xr[NL], xi[NL], yr[NL], yi[NL];
+#if !ZKP_KSQ_ASM
     auto advance = [&](const int32_t* mr, const int32_t* mi, const int32_t* o_r, const int32_t* oi) {
         park_st(parked, lane, mr, mi);            // the "2 z" term of the lane's next combination
         if (b_lane) {
@@ -616,6 +621,7 @@ __global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t
             }
         }
     };
+#endif
     {
         Fp28 u0, u1, v0, v1;
         rec_load(u0, rec(elem_in + 2 * tu));
