@@ -1343,10 +1343,13 @@ def emu_kdec_b(state, elem_snap, count, elem_ninv):
         dinv = (mont_mul([(D[0], ninv)]), mont_mul([([-x for x in D[1]], ninv)]))
         z1 = c2_mul(N, dinv)
         z2, z3, z4, z5 = (_snap_fp2(state, base, pos) for pos in (3, 2, 1, 5))
-        t = c2_add(c2_dbl(c2_sqr(z1)), c2_mul(z2, z5))
-        m34 = c2_mul(z3, z4)
-        t = c2_sub(t, c2_add(c2_dbl(m34), m34))
-        t = (vred(t[0]), vred(t[1]))
+        # t = 2 z1^2 + z2 z5 - 3 z3 z4 under ONE reduction per coefficient (zkp_coop.hip k_kdec_b): five products each
+        neg = lambda v: [-x for x in v]
+        k3 = lambda v: [-3 * x for x in v]
+        t = (mont_mul([([2 * (x + y) for x, y in zip(z1[0], z1[1])], [x - y for x, y in zip(z1[0], z1[1])]),
+                       (z2[0], z5[0]), (neg(z2[1]), z5[1]), (k3(z3[0]), z4[0]), (neg(k3(z3[1])), z4[1])]),
+             mont_mul([([4 * x for x in z1[0]], z1[1]),
+                       (z2[0], z5[1]), (z2[1], z5[0]), (k3(z3[0]), z4[1]), (k3(z3[1]), z4[0])]))
         xt = c2_xi(t)
         z0 = (vred(_c_lin(xt[0], one[0], 1)), vred(xt[1]))
         state[base + 0], state[base + 1] = z0

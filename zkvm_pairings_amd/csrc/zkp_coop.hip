@@ -844,6 +844,32 @@ __device__ __attribute__((noinline)) Fp28 c_mul_q(Fp28 ma, int4 q0, int4 q1, int
     return r;
 }
 __device__ __forceinline__ Fp28 c_mul(const Fp28& ma, const Fp28& mb, int c) { return c_mul_q(ma, FP28_AS_QUADS(mb), c); }
+// r = coefficient c of s^2 - 12 e^2 with ONE reduction (the Y' = (B + F)^2 - 3 (2 E)^2 of the homogeneous doubling step): both
+// squarings' operand forms as in c_sqr, the second product's first factor normalised (one pass) and scaled by -12.
+// Column budget (units of 2^54 per product of limbs): s normalised, e renormalised: 2 * 2 + 12 * 2 = 28 <= 30.
+__device__ __attribute__((noinline)) Fp28 c_sqr_sub12sqr_q(Fp28 s, int4 q0, int4 q1, int4 q2, int4 q3, int c) {
+    Fp28 e, os, oe, r;
+    fp28_unpack(e, q0, q1, q2, q3);
+    swap_pair(os, s);
+    swap_pair(oe, e);
+    int32_t xs[NL], ys[NL], xe[NL], ye[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        xs[i] = os.l[i] + (c ? os.l[i] : s.l[i]);
+        ys[i] = s.l[i] - (c ? 0 : os.l[i]);
+        xe[i] = oe.l[i] + (c ? oe.l[i] : e.l[i]);
+        ye[i] = e.l[i] - (c ? 0 : oe.l[i]);
+    }
+    weak_norm(xe);
+#pragma unroll
+    for (int i = 0; i < NL; i++) xe[i] *= -12;
+    Acc acc;
+    acc_zero(acc);
+    acc_mul(acc, xs, ys);
+    acc_mul(acc, xe, ye);
+    acc_reduce(r.l, acc);
+    return r;
+}
 __device__ __attribute__((noinline)) Fp28 f_mul_q(Fp28 a, int4 q0, int4 q1, int4 q2, int4 q3) {
     Fp28 b, r;
     fp28_unpack(b, q0, q1, q2, q3);
@@ -948,6 +974,14 @@ __device__ __forceinline__ BdRed bd_mul(const Bd<L1, A1, B1>& a, const Bd<L2, A2
     r.v = c_mul(a.v, b.v, c);
     return r;
 }
+// a^2 - 12 e^2, one reduction (c_sqr_sub12sqr_q): a normalised, e renormalised
+template <int A, int B>
+__device__ __forceinline__ BdRed bd_sqr_sub12sqr(const Bd<1, A, B>& a, const BdVred& e, int c) {
+    static_assert(4 * bd_k(A, B) * bd_k(A, B) + 12 * 4 * 33 * 33 <= 100 * 64 * 64, "value budget of the reduction");
+    BdRed r;
+    r.v = c_sqr_sub12sqr_q(a.v, FP28_AS_QUADS(e.v), c);
+    return r;
+}
 // static checks for values that leave the typed code as plain Fp28
 template <int L, int A, int B>
 __device__ __forceinline__ const Fp28& bd_for_vred(const Bd<L, A, B>& a) {
@@ -1033,7 +1067,8 @@ __device__ __forceinline__ void add_step(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, c
 //   B = Y^2, C = W^2, H2 = (Y + W)^2 - B - C = 2 Y W, E = 3 xi C, F = 3 E,
 //   X' = ((X + Y)^2 - X^2 - B) (B - F) = 2 X Y (B - F),   Y' = (B + F)^2 - 3 (2 E)^2,   W' = 4 B H2
 //   line (times 2 / Z): 2 (B - E)  -  6 X^2 xP  +  H2 yP        [the (c0, c1, c4) operands of mul_by_014]
-// Seven Fp2 squarings and two products: 13 products and 11 reductions per lane against 16 and 13 of Alg. 26.
+// Seven Fp2 squarings and two products: 13 products and 10 reductions per lane (the two squarings of Y' share one) against
+// 16 and 13 of Alg. 26.
 template <int L, int A, int B>
 __device__ __forceinline__ Bd<2 * L, (A - B), (A + B) < 2 * B ? 2 * B : (A + B)> bd_xi(const Bd<L, A, B>& a, int c) {
     // (1 + u) (a0 + a1 u) = (a0 - a1) + (a0 + a1) u : this lane's coefficient, the partner's by DPP
@@ -1054,7 +1089,7 @@ __device__ __forceinline__ void dbl_step_cln(G2C& r, int c, S0&& sink_l0, S1&& s
     auto C = bd_sqr(w, c);
     auto H2 = bd_sub(bd_sub(bd_sqr(bd_add(y, w), c), B), C);
     sink_l0(bd_for_fmul(H2));
-    auto nw = bd_dbl(bd_dbl(bd_mul(B, H2, c)));
+    auto nw = bd_mul(B, bd_dbl(bd_dbl(H2)), c);      // 4 B H2 with the factor on the operand: a reduced product, no renormalisation
     auto xiC = bd_xi(C, c);
     auto E = bd_vred(bd_add(bd_add(xiC, xiC), xiC));
     sink_l2(bd_for_vred(bd_dbl(bd_sub(B, E))));
@@ -1066,12 +1101,10 @@ __device__ __forceinline__ void dbl_step_cln(G2C& r, int c, S0&& sink_l0, S1&& s
     auto XY2 = bd_sub(bd_sub(bd_sqr(bd_add(x, y), c), X2), B);
     auto F = bd_add(bd_add(E, E), E);
     auto nx = bd_mul(XY2, bd_sub(B, F), c);
-    auto S = bd_sqr(bd_norm(bd_add(B, F)), c);
-    auto T = bd_sqr(bd_dbl(E), c);
-    auto ny = bd_sub(S, bd_add(bd_add(T, T), T));
+    auto ny = bd_sqr_sub12sqr(bd_norm(bd_add(B, F)), E, c);      // (B + F)^2 - 3 (2 E)^2 under one reduction
     r.x = nx.v;                 // a reduced product is a valid input as it stands
-    r.y = bd_vred(ny).v;
-    r.z = bd_vred(nw).v;
+    r.y = ny.v;
+    r.z = nw.v;
 }
 // mixed addition T + Q on the same coordinates (Aranha et al. eq. (13), (14) with every quantity doubled: W = 2 Z):
 //   th = 2 Y - y2 W, la = 2 X - x2 W, C = th^2, D = la^2, E = la D, F = W C, G = 2 X D, H = E + F - 2 G,
@@ -1686,6 +1719,9 @@ __global__ void __launch_bounds__(64, 2) k_kdec_a(int4* state, uint32_t n_checks
         if (c == 0) rec_store(rec(elem_n + sn), n);
     }
 }
+#ifndef ZKP_KDEC_MERGED
+#define ZKP_KDEC_MERGED 1
+#endif
 __global__ void __launch_bounds__(64, 2) k_kdec_b(int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_snap, uint32_t count, uint32_t elem_ninv) {
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
     const int c = (int)(tid & 1);
@@ -1703,6 +1739,54 @@ __global__ void __launch_bounds__(64, 2) k_kdec_b(int4* state, uint32_t n_checks
     rec_load(ninv, rec(elem_ninv + sn));
     Fp28 dinv = f_mul_v(c ? c_neg(D) : D, ninv);               // conj(D) / |D|^2
     Fp28 z1 = f.mul(N, dinv);
+#if ZKP_KDEC_MERGED
+    // t = 2 z1^2 + z2 z5 - 3 z3 z4 under ONE reduction (five products; column budget 2 * 2 * 2 + 2 + 3 * 2 = 16 <= 30; a reduced
+    // value, no renormalisation): coefficient c of a b is x1 b + x2 b' with (x1, x2) = (a, -a') or (a', a), ' = the partner's
+    Fp28 t;
+    {
+        Acc acc;
+        acc_zero(acc);
+        auto mulacc = [&](const Fp28& a, const Fp28& b, int k) {
+            Fp28 ao, bo;
+            swap_pair(ao, a);
+            swap_pair(bo, b);
+            int32_t x1[NL], x2[NL];
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                x1[i] = k * (c ? ao.l[i] : a.l[i]);
+                x2[i] = k * (c ? a.l[i] : -ao.l[i]);
+            }
+            acc_mul(acc, x1, b.l);
+            acc_mul(acc, x2, bo.l);
+        };
+        {
+            Fp28 o1;
+            swap_pair(o1, z1);
+            int32_t x[NL], y[NL];
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                x[i] = 2 * (o1.l[i] + (c ? o1.l[i] : z1.l[i]));
+                y[i] = z1.l[i] - (c ? 0 : o1.l[i]);
+            }
+            acc_mul(acc, x, y);
+        }
+        {
+            Fp28 z2, z5;
+            rec_load(z2, rec(base + 6 + c));
+            rec_load(z5, rec(base + 10 + c));
+            mulacc(z2, z5, 1);
+        }
+        {
+            Fp28 z3, z4;
+            rec_load(z3, rec(base + 4 + c));
+            rec_load(z4, rec(base + 2 + c));
+            mulacc(z3, z4, -3);
+        }
+        acc_reduce(t.l, acc);
+    }
+    Fp28 o;
+    swap_pair(o, t);
+#else
     Fp28 z2, z3, z4, z5;
     rec_load(z2, rec(base + 6 + c));
     rec_load(z5, rec(base + 10 + c));
@@ -1713,6 +1797,7 @@ __global__ void __launch_bounds__(64, 2) k_kdec_b(int4* state, uint32_t n_checks
     t = f_vred(c_sub(t, c_add(c_dbl(m34), m34)));
     Fp28 o;
     swap_pair(o, t);
+#endif
     Fp28 z0 = c ? c_add(o, t) : c_add(c_sub(t, o), f_const(K28_ONE));   // xi t + 1
     z0 = f_vred(z0);
     if (live) {
