@@ -355,38 +355,6 @@ def kterm(g, A, B, first):
             acc(("m", i + j), g.MID[i + j], D + i, D + NH + j)
 
 
-def generate_fp2mul(vb=6):
-    g = Fp2Mul(vb)
-    kterm(g, g.XR, g.YI, True)
-    kterm(g, g.XI, g.YR, False)
-    tail(g, g.S)
-    for i in range(NL):
-        g.e("v_sub_u32 v%d, 0, v%d" % (g.XI + i, g.XI + i))
-    kterm(g, g.XR, g.YR, True)
-    kterm(g, g.XI, g.YI, False)
-    tail(g, g.XR)
-    return g
-
-
-def write_fp2mul(f, vb=6):
-    g = generate_fp2mul(vb)
-    n = sum(1 for l in g.lines if not l.endswith(":"))
-    f.write("// The Fp2 product of k_ksq: %d instructions; VGPRs v%d..v%d.\n" % (n, g.vb, g.vend - 1))
-    f.write("#define ZKP_FP2MUL_ASM \\\n")
-    for l in g.lines:
-        f.write('    "%s\\n\\t" \\\n' % l)
-    f.write('    ""\n')
-    f.write("// operands: xr (in) / real part (out), xi (in, destroyed), the imaginary part (out); then the inputs yr, yi\n")
-    f.write("#define ZKP_FP2MUL_OUTS(xr, xi, sim) " + ", ".join('"+{v%d}"((xr)[%d])' % (g.XR + i, i) for i in range(NL)) + ", "
-            + ", ".join('"+{v%d}"((xi)[%d])' % (g.XI + i, i) for i in range(NL)) + ", "
-            + ", ".join('"={v%d}"((sim)[%d])' % (g.S + i, i) for i in range(NL)) + "\n")
-    f.write("#define ZKP_FP2MUL_INS(yr, yi) " + ", ".join('"{v%d}"((yr)[%d])' % (g.YR + i, i) for i in range(NL)) + ", "
-            + ", ".join('"{v%d}"((yi)[%d])' % (g.YI + i, i) for i in range(NL)) + "\n")
-    f.write("#define ZKP_FP2MUL_CLOBBERS " + ", ".join('"v%d"' % v for v in range(g.D, g.vend)) + ", "
-            + ", ".join('"s%d"' % x for x in range(g.sb, g.send)) + ', "scc"\n')
-    return g
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # k_ksq: one compressed squaring per loop iteration.  The block continues the Fp2 product above with everything that
 # follows it in the iteration except the rare snapshot store and the operand forms of the next product (C++):

@@ -510,8 +510,10 @@ __device__ __forceinline__ void rec_load(Fp28& x, const int4* src) {
 // step program multiplies them.  tools/coopgen.py emu_ksq / emu_kdec are the limb-exact models of these kernels.
 constexpr int KS_CHECKS = 16;
 #ifndef ZKP_KSQ_ASM
-#define ZKP_KSQ_ASM ZKP_COOP_ASM   // the Fp2 product of k_ksq as the interpreter's Karatsuba term + tail on register operands (tools/coopasm.py:
-                                   // 980 multiply-adds instead of the 1,204 of two product-scanning multiplies); 0: mont_mul_ps, the A/B baseline
+#define ZKP_KSQ_ASM ZKP_COOP_ASM   // a squaring of k_ksq behind its operand forms as ONE asm block (tools/coopasm.py generate_ksq): the Fp2 product
+                                   // as Karatsuba terms + tail on register operands (980 multiply-adds instead of the 1,204 of two
+                                   // product-scanning multiplies), DPP combinations, both carry chains, parking; 0: the compiled loop
+                                   // around mont_mul_ps, the A/B baseline
 #endif
 #ifndef ZKP_KSQ_WAVES
 #if ZKP_KSQ_ASM
