@@ -1,0 +1,128 @@
+"""CPU gate for the asm doubling step of k_prep_lines<true> (tools/prepasm.py): the generated instruction text, executed by
+tools/asmemu.py on the two lanes of one pair, must give the values of the Costello-Lange-Naehrig doubling formulas in
+big-integer arithmetic - the new point, the three line coefficients it stores - inside the bounds the next step needs."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import asmemu  # noqa: E402
+import coopgen as cg  # noqa: E402
+import prepasm  # noqa: E402
+
+NL = 14
+P = cg.P
+
+
+def f2mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def f2add(a, b):
+    return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+
+
+def f2sub(a, b):
+    return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+
+
+def f2k(a, k):
+    return ((a[0] * k) % P, (a[1] * k) % P)
+
+
+def f2xi(a):
+    return ((a[0] - a[1]) % P, (a[0] + a[1]) % P)
+
+
+def doubling_model(X, Y, W, xP, yP):
+    B, C = f2mul(Y, Y), f2mul(W, W)
+    YW = f2add(Y, W)
+    H2 = f2sub(f2sub(f2mul(YW, YW), B), C)
+    E = f2k(f2xi(C), 3)
+    F = f2k(E, 3)
+    X2 = f2mul(X, X)
+    XY = f2add(X, Y)
+    XY2 = f2sub(f2sub(f2mul(XY, XY), X2), B)
+    nx = f2mul(XY2, f2sub(B, F))
+    BF = f2add(B, F)
+    ny = f2sub(f2mul(BF, BF), f2k(f2mul(E, E), 12))
+    nw = f2mul(B, f2k(H2, 4))
+    l2 = f2k(f2sub(B, E), 2)
+    l1 = f2k(f2k(X2, -6), xP)
+    l0 = f2k(H2, yP)
+    return nx, ny, nw, (l2, l1, l0)
+
+
+def _subst():
+    s = {"p%d" % i: (P >> (28 * i)) & 0xfffffff for i in range(NL)}
+    s["pinv"] = (-pow(P, -1, 1 << 28)) % (1 << 28)
+    s.update({"estride": "s110", "voff": "v1", "smask": "s[112:113]", "base": "s[114:115]"})
+    return s
+
+
+def test_doubling_step_block_equals_the_formulas():
+    rng = random.Random(99)
+    g = prepasm.generate()
+    for trial in range(4):
+        # reduced inputs as the previous step leaves them: values in (-0.05 p, 1.05 p); trial 0: the first step (W = 2, X, Y < p)
+        def rv():
+            return rng.randrange(P) if trial % 2 == 0 else rng.randrange(P) - P // 20
+
+        X, Y = (rv(), rv()), (rv(), rv())
+        W = (2, 0) if trial == 0 else (rv(), rv())
+        xP, yP = rng.randrange(P), rng.randrange(P)
+
+        def limbs(v):           # Montgomery form of the VALUE v (which may be a little outside [0, p)), balanced limbs
+            sh = (v // P) * P if v < 0 or v >= P else 0
+            l = cg.mont(v - sh)
+            if sh:
+                add = cg.to_limbs_balanced(sh)
+                l = cg.weak_norm([a + b for a, b in zip(l, add)])
+            return l
+
+        emu = asmemu.Emu(lanes=2, subst=_subst())
+        for c in range(2):
+            for base, val in ((g.X, X), (g.Y, Y), (g.W, W)):
+                for i, x in enumerate(cg.mont(val[c] % P)):
+                    emu.v.setdefault(base + i, [None, None])[c] = x & asmemu.M32
+        nc = 7
+        estride = 2 * nc * 64
+        emu.s[110] = estride
+        emu.s[112], emu.s[113] = 0xffffffff, 0xffffffff
+        emu.s[114], emu.s[115] = 0x100000, 0
+        emu.v[1] = [0, nc * 64]                      # lane c writes record e + c
+        for v, val in ((0, xP), (1, yP)):
+            l = cg.mont(val)
+            for lane in range(2):
+                for i in range(NL):
+                    emu.lds[(v * 4 + i // 4) * 1024 + 16 * lane + 4 * (i % 4)] = l[i] & asmemu.M32
+                for i in (14, 15):
+                    emu.lds[(v * 4 + 3) * 1024 + 16 * lane + 4 * (i % 4)] = 0
+        emu.run(g.lines)
+        assert emu.exec == 3
+        nx, ny, nw, lines = doubling_model(X, Y, W, xP, yP)
+
+        def out(base):
+            ls = [[asmemu.s32(emu.v[base + i][c]) for i in range(NL)] for c in range(2)]
+            for l in ls:
+                assert all(abs(x) <= (1 << 27) + 16 for x in l[:NL - 1]), "limb bound of a reduced value"
+                assert -0.06 * P < cg.limbs_value(l) < 1.06 * P, "value bound of a reduced value"
+            return tuple(cg.from_mont(l) for l in ls)
+
+        assert out(g.X) == nx and out(g.Y) == ny and out(g.W) == nw, trial
+        for k, want in enumerate(lines):             # records 0, 2, 4 (+ c)
+            for c in range(2):
+                addr = 0x100000 + (2 * k + c) * nc * 64
+                l = [asmemu.s32(emu.mem[addr + 4 * i]) for i in range(NL)]
+                assert emu.mem[addr + 56] == 0 and emu.mem[addr + 60] == 0
+                assert all(abs(x) <= (1 << 27) + 16 for x in l[:NL - 1])
+                assert abs(cg.limbs_value(l)) < 1.06 * P
+                assert cg.from_mont(l) == want[c], (trial, k, c)
+
+
+def test_generated_file_is_current():
+    inc = open(os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_prep_dbl.inc")).read()
+    g = prepasm.generate()
+    assert all(('"%s\\n\\t"' % l) in inc for l in g.lines[:60] + g.lines[-60:]), "zkp_prep_dbl.inc is not what tools/prepasm.py generates"

@@ -41,6 +41,7 @@ class Emu:
         self.lds = {}               # byte address -> dword (addresses are multiples of 4)
         self.mem = {}               # global memory: byte address -> dword
         self.scc = 0
+        self.vcc = 0
         self.subst = dict(subst or {})
         self.strict = strict
         self.count = {}
@@ -181,6 +182,9 @@ class Emu:
         self.s[int(a[0][1:])] = int(a[1], 0) & M32 if not a[1].startswith("s") else self.s[int(a[1][1:])]
 
     def op_s_mov_b64(self, a, m):
+        if a[0] == "vcc":
+            self.vcc = self.rd(a[1], 0)
+            return
         if a[0] == "exec":
             self.exec = self.rd(a[1], 0) & ((1 << self.n) - 1) if a[1] != "-1" else (1 << self.n) - 1
             return
@@ -248,6 +252,16 @@ class Emu:
         mm = re.fullmatch(r"v\[(\d+):(\d+)\]", op.strip())
         return int(mm.group(1)) if mm else int(op.strip()[1:])
 
+    def op_global_store_dwordx4(self, a, m):     # voffset, vdata[4], saddr
+        base = self.rd(a[2], 0)
+        for lane in range(self.n):
+            if (self.exec >> lane) & 1:
+                addr = base + self.rd(a[0], lane) + m.get("offset", 0)
+                assert addr % 16 == 0
+                val = self.rd(a[1], lane, 4)
+                for k in range(4):
+                    self.mem[addr + 4 * k] = (val >> (32 * k)) & M32
+
     def op_global_load_dwordx3(self, a, m):
         self._gload(a, m, 3)
 
@@ -289,6 +303,10 @@ class Emu:
     # ---- vector
     def op_v_mov_b32(self, a, l, sl):
         self.wr(a[0], l, self.rd(a[1], sl))
+
+    def op_v_cndmask_b32(self, a, l, sl):        # d = vcc[lane] ? src1 : src0
+        assert a[3].strip() == "vcc"
+        self.wr(a[0], l, self.rd(a[2], l) if (self.vcc >> l) & 1 else self.rd(a[1], l))
 
     def op_v_add_u32(self, a, l, sl):
         self.wr(a[0], l, self.rd(a[1], sl) + self.rd(a[2], l))

@@ -43,6 +43,13 @@
 #if ZKP_COOP_ASM
 #include "zkp_coop_mulacc.inc"
 #endif
+#ifndef ZKP_PREP_ASM
+#define ZKP_PREP_ASM ZKP_COOP_ASM   // the doubling step of k_prep_lines<true> as one hand-allocated asm block (tools/prepasm.py ->
+                                    // zkp_prep_dbl.inc); 0: the compiled step (dbl_step_cln), the A/B baseline
+#endif
+#if ZKP_PREP_ASM
+#include "zkp_prep_dbl.inc"
+#endif
 
 using namespace zkp28;
 
@@ -1153,7 +1160,7 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
     auto rec = [&](uint32_t step, uint32_t e) -> int4* { return lines + ((((size_t)step * k + j) * 6 + e) * nc + check) * 4; };
     // P = (px, py) and Q = (qx, qy) are needed once per step / five times per loop: parked in LDS (limb quad q of
     // value v at [(v * 4 + q) * 64 + lane], conflict-free) instead of occupying 56 VGPRs across every call
-    __shared__ int4 park[4 * 4 * 64];
+    extern __shared__ int4 park[];           // 4 values x 4 quads x 64 lanes, at LDS address 0 (the asm step reads xP, yP by lane number)
     const int lane = threadIdx.x;
     enum { PX = 0, PY = 1, QX = 2, QY = 3 };
     auto park_st = [&](int v, const Fp28& x) {
@@ -1207,7 +1214,29 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
     const uint64_t xs = 0xd201000000010000ULL;
 #pragma unroll 1
     for (int b = 62; b >= 0; b--) {
+#if ZKP_PREP_ASM
+        if (CLN) {
+            // the step's three line records leave from inside the block (lanes of live pairs without an infinity); a pair with
+            // an infinity gets the neutral line from put() below
+            static_assert(NL == 14, "the generated block is for 14 limbs");
+            constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};
+            const unsigned long long smask = __ballot(live_lane && !dead);
+            const char* const sbase = (const char*)lines + (size_t)step * k * 6 * nc * 64;
+            const uint32_t voff = (uint32_t)(((size_t)j * 6 + c) * nc + check) * 64u;
+            asm volatile(ZKP_PREP_DBL_ASM
+                         : ZKP_PREP_DBL_IO(r.x.l, r.y.l, r.z.l)
+                         : [estride] "s"(2u * nc * 64u), [voff] "v"(voff), [smask] "s"(smask), [base] "s"(sbase),
+                           [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]), [p6] "s"(PL[6]),
+                           [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]), [p12] "s"(PL[12]),
+                           [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)
+                         : ZKP_PREP_DBL_CLOBBERS);
+            if (dead) { put(4, r.x); put(2, r.x); put(0, r.x); }
+        } else {
+            dbl_step(r, c, sink_l0, sink_l1, sink_l2);
+        }
+#else
         if (CLN) dbl_step_cln(r, c, sink_l0, sink_l1, sink_l2); else dbl_step(r, c, sink_l0, sink_l1, sink_l2);
+#endif
         step++;
         if ((xs >> b) & 1) {
             Fp28 l0, l1, l2;
@@ -2053,10 +2082,10 @@ static hipError_t prep(CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, con
     uint32_t n_pairs = n * g;
     static const char* no_cln = getenv("ZKP_PREP_NO_CLN");   // A/B knob
     if (fused && !(no_cln && atoi(no_cln)))
-        hipLaunchKernelGGL(k_prep_lines<true>, dim3((2 * n_pairs + 63) / 64), dim3(64), 0, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
+        hipLaunchKernelGGL(k_prep_lines<true>, dim3((2 * n_pairs + 63) / 64), dim3(64), 4 * 4 * 64 * sizeof(int4), s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
                            i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines);
     else
-        hipLaunchKernelGGL(k_prep_lines<false>, dim3((2 * n_pairs + 63) / 64), dim3(64), 0, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
+        hipLaunchKernelGGL(k_prep_lines<false>, dim3((2 * n_pairs + 63) / 64), dim3(64), 4 * 4 * 64 * sizeof(int4), s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
                            i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines);
     return hipGetLastError();
 }
