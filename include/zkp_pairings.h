@@ -221,6 +221,11 @@ int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1,
  * overlaps the kernels and the other contexts' copies.  zkp_host_alloc returns page-locked memory usable with every
  * context / GPU of the process (hipHostMallocPortable); zkp_host_register page-locks an existing allocation in place
  * (hipHostRegister: slow, of the order of 1 ms per 4 MB - do it once for a buffer that is reused, not per call).  The
+ * registered range must consist of WHOLE PAGES of its own: ptr and bytes multiples of the page size (4096), i.e. memory
+ * from posix_memalign / aligned_alloc / mmap, not a slice of the malloc heap - the driver locks and maps pages, and two
+ * registrations that share a page (two neighbouring heap arrays) left the HIP runtime with a stale entry after the
+ * unregistration: a later copy from a reused heap address then went to the GPU as a DMA from an unmapped page (a GPU
+ * memory fault; found in round 3).  Anything else is ZKP_ERR_ARG.  The
  * entry points themselves accept either kind of memory and give the same results.  No reference counterpart: the
  * reference is a host-only crate (its point arrays would live in a Vec; the Rust wrapper's PinnedVec in
  * integration/rust/src/lib.rs is the drop-in container). */

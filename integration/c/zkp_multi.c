@@ -53,7 +53,10 @@ int main(int argc, char** argv) {
 
     /* pairs (a_i G1, b_i G2) with small distinct scalars, made on the GPU */
     uint64_t* sc = calloc(4 * n, 8), *sb = calloc(4 * n, 8);
-    uint64_t* g1 = malloc(96 * n), *g2 = malloc(192 * n);
+    /* whole pages of their own, so that they can be page-locked in place below (zkp_host_register takes nothing else) */
+    const size_t b1 = (96 * n + 4095) / 4096 * 4096, b2 = (192 * n + 4095) / 4096 * 4096;
+    uint64_t* g1 = aligned_alloc(4096, b1), *g2 = aligned_alloc(4096, b2);
+    CHECK(g1 && g2, "aligned_alloc failed");
     for (size_t i = 0; i < n; i++) { sc[4 * i] = 3 + 2 * i; sc[4 * i + 1] = 0x9e3779b97f4a7c15ULL * (i + 1); sb[4 * i] = 5 + 7 * i; }
     CHECK(zkp_g1_mul_batch(ctx[0], G1, 0, sc, n, g1, NULL) == ZKP_OK, "g1 mul: %s", zkp_last_error(ctx[0]));
     CHECK(zkp_g2_mul_batch(ctx[0], G2, 0, sb, n, g2, NULL) == ZKP_OK, "g2 mul: %s", zkp_last_error(ctx[0]));
@@ -68,7 +71,7 @@ int main(int argc, char** argv) {
     CHECK(all == 0, "random pairings must not all be the identity");
     for (size_t i = 0; i < n; i++) CHECK(okm[i] == 0, "pairing %zu reported as identity", i);
 
-    /* the same call from page-locked memory (zkp_host_alloc) and from the malloc'ed arrays page-locked in place
+    /* the same call from page-locked memory (zkp_host_alloc) and from the page-aligned arrays page-locked in place
      * (zkp_host_register): same Gt; the copies are then DMAs that overlap the kernels and the other contexts' copies */
     {
         void *p1 = NULL, *p2 = NULL, *pg = NULL;
@@ -86,7 +89,8 @@ int main(int argc, char** argv) {
         CHECK(memcmp(gt1, pg, 576 * n) == 0, "Gt from page-locked arrays differs");
         printf("zkp_pairing_batch_multi, %zu pairs, Gt out: %.2f ms from pageable memory, %.2f ms from zkp_host_alloc memory\n", n,
                (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6);
-        CHECK(zkp_host_register(g1, 96 * n) == ZKP_OK && zkp_host_register(g2, 192 * n) == ZKP_OK, "zkp_host_register failed");
+        CHECK(zkp_host_register(g1, b1) == ZKP_OK && zkp_host_register(g2, b2) == ZKP_OK, "zkp_host_register failed");
+        CHECK(zkp_host_register((char*)gt1 + 8, 4096) == ZKP_ERR_ARG, "a range that is not whole pages must be refused");
         memset(gtm, 0, 576 * n);
         CHECK(zkp_pairing_batch_multi(ctx, n_ctx, g1, g2, NULL, NULL, n, gtm, NULL, NULL) == ZKP_OK, "multi pairing (registered) failed");
         CHECK(memcmp(gt1, gtm, 576 * n) == 0, "Gt from registered arrays differs");

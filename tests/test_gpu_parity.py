@@ -557,17 +557,27 @@ def test_page_locked_host_arrays(monkeypatch):
         with pytest.raises(ValueError):
             e.pairing(p1, p2, out=np.empty((n, 71), dtype=np.uint64))
         lib = _lib.load()
-        r1, r2 = np.array(g1), np.array(g2)
-        assert lib.zkp_host_register(ctypes.c_void_p(r1.ctypes.data), r1.nbytes) == 0
-        assert lib.zkp_host_register(ctypes.c_void_p(r2.ctypes.data), r2.nbytes) == 0
+        # zkp_host_register takes whole pages of their own (anonymous mappings here): two registered heap arrays that shared a page
+        # left the HIP runtime with a stale entry, and a later copy from a reused heap address became a GPU memory fault
+        import mmap
+        m1, m2 = mmap.mmap(-1, (g1.nbytes + 4095) // 4096 * 4096), mmap.mmap(-1, (g2.nbytes + 4095) // 4096 * 4096)
+        r1 = np.frombuffer(m1, dtype=np.uint64, count=g1.size).reshape(g1.shape)
+        r2 = np.frombuffer(m2, dtype=np.uint64, count=g2.size).reshape(g2.shape)
+        r1[:], r2[:] = g1, g2
+        assert lib.zkp_host_register(ctypes.c_void_p(r1.ctypes.data), len(m1)) == 0
+        assert lib.zkp_host_register(ctypes.c_void_p(r2.ctypes.data), len(m2)) == 0
         try:
             assert np.array_equal(e.pairing(r1, r2), want)
         finally:
             assert lib.zkp_host_unregister(ctypes.c_void_p(r1.ctypes.data)) == 0
             assert lib.zkp_host_unregister(ctypes.c_void_p(r2.ctypes.data)) == 0
+        heap = np.array(g1)
+        assert lib.zkp_host_register(ctypes.c_void_p(heap.ctypes.data + 8), 4096) == -1       # not whole pages: ZKP_ERR_ARG
         p = ctypes.c_void_p()
         assert lib.zkp_host_alloc(0, ctypes.byref(p)) == -1 and lib.zkp_host_free(None) == 0      # ZKP_ERR_ARG; free(NULL) is a no-op
-        del p1, p2, pg, got
+        del p1, p2, pg, got, r1, r2
+        m1.close()
+        m2.close()
     finally:
         e.close()
 

@@ -32,7 +32,7 @@ QP = "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
 
 
 class Prep:
-    def __init__(self, vb=10):
+    def __init__(self, vb=6):
         self.lines = []
         v = vb
         assert v % 2 == 0
@@ -59,7 +59,7 @@ class Prep:
         self.voff = v; v += 1                  # store offset of the current record
         self.vq = v; v += 1                    # renormalisation quotient
         self.vt = v; v += 1
-        self.vc = v; v += 14                   # carries of the one-pass normalisation
+        self.vc = self.D                       # carries of the one-pass normalisation: the difference block is free between products
         self.vend = v
         assert self.vend <= 256, self.vend
         s = 36
@@ -209,7 +209,7 @@ class Prep:
         self.all_lanes()
 
 
-def generate(vb=10):
+def generate(vb=6):
     g = Prep(vb)
     X, Y, W = g.X, g.Y, g.W
     V0, V1, V2 = g.V
@@ -284,7 +284,7 @@ def generate(vb=10):
     return g
 
 
-def write_inc(path, vb=10):
+def write_inc(path, vb=6):
     g = generate(vb)
     n = sum(1 for l in g.lines if not l.endswith(":"))
     io = []

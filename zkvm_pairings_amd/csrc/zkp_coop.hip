@@ -856,7 +856,7 @@ __device__ __forceinline__ Fp28 c_mul(const Fp28& ma, const Fp28& mb, int c) { r
 // r = coefficient c of s^2 - 12 e^2 with ONE reduction (the Y' = (B + F)^2 - 3 (2 E)^2 of the homogeneous doubling step): both
 // squarings' operand forms as in c_sqr, the second product's first factor normalised (one pass) and scaled by -12.
 // Column budget (units of 2^54 per product of limbs): s normalised, e renormalised: 2 * 2 + 12 * 2 = 28 <= 30.
-__device__ __attribute__((noinline)) Fp28 c_sqr_sub12sqr_q(Fp28 s, int4 q0, int4 q1, int4 q2, int4 q3, int c) {
+[[maybe_unused]] __device__ __attribute__((noinline)) Fp28 c_sqr_sub12sqr_q(Fp28 s, int4 q0, int4 q1, int4 q2, int4 q3, int c) {
     Fp28 e, os, oe, r;
     fp28_unpack(e, q0, q1, q2, q3);
     swap_pair(os, s);
@@ -1943,6 +1943,9 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
         std::vector<uint4> rt;
         coop_resolve_table(p, rt);
         if ((e = hipMalloc((void**)&d->progs[i].rtbl, rt.size() * sizeof(uint4))) != hipSuccess) return e;
+        zkp_dbg_alloc("prog.hdr", d->progs[i].hdr, p.n_hdr * 4);
+        zkp_dbg_alloc("prog.tbl", d->progs[i].tbl, (p.n_tbl + 2 * LIG + 4) * 4);
+        zkp_dbg_alloc("prog.rtbl", d->progs[i].rtbl, rt.size() * sizeof(uint4));
         if ((e = hipMemcpy(d->progs[i].rtbl, rt.data(), rt.size() * sizeof(uint4), hipMemcpyHostToDevice)) != hipSuccess) return e;
     }
     if ((e = hipMalloc((void**)&d->consts, sizeof(ZKP_COOP_CONSTS))) != hipSuccess) return e;
@@ -2011,7 +2014,7 @@ static hipError_t ensure_buf(int4** p, size_t* cap, size_t bytes) {
     if (bytes <= *cap) return hipSuccess;
     if (*p) { hipError_t e = hipFree(*p); if (e != hipSuccess) return e; *p = nullptr; *cap = 0; }
     hipError_t e = hipMalloc((void**)p, bytes);
-    if (e == hipSuccess) *cap = bytes;
+    if (e == hipSuccess) { *cap = bytes; zkp_dbg_alloc("coop.buf", *p, bytes); }
     return e;
 }
 

@@ -41,3 +41,16 @@ hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, c
                         size_t k, uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s);
 
 }  // namespace zkp
+
+// debugging aid: ZKP_DEBUG_ALLOC=<file> appends one line per device / pinned allocation and release (address, bytes, what for), so
+// that the address of a GPU memory fault can be matched to a buffer
+#include <cstdio>
+#include <cstdlib>
+static inline void zkp_dbg_alloc(const char* what, const void* p, size_t bytes) {
+    static const char* path = getenv("ZKP_DEBUG_ALLOC");
+    if (!path) return;
+    if (FILE* f = fopen(path, "a")) {
+        fprintf(f, "%s %p %zu\n", what, p, bytes);
+        fclose(f);
+    }
+}

@@ -389,6 +389,7 @@ int ensure(zkp_ctx* c, int slot, size_t bytes) {
     if (bytes <= c->cap[slot]) return ZKP_OK;
     if (c->buf[slot]) { HIPCHK(c, hipFree(c->buf[slot])); c->buf[slot] = nullptr; c->cap[slot] = 0; }
     HIPCHK(c, hipMalloc(&c->buf[slot], bytes));
+    zkp_dbg_alloc(slot == 0 ? "ctx.buf0" : slot == 1 ? "ctx.buf1" : slot == 4 ? "ctx.buf4" : "ctx.buf", c->buf[slot], bytes);
     c->cap[slot] = bytes;
     return ZKP_OK;
 }
@@ -456,6 +457,7 @@ int ensure_prod(zkp_ctx* c, size_t records) {
     if (bytes <= c->prod_cap) return ZKP_OK;
     if (c->prod) { HIPCHK(c, hipFree(c->prod)); c->prod = nullptr; c->prod_cap = 0; }
     HIPCHK(c, hipMalloc((void**)&c->prod, bytes));
+    zkp_dbg_alloc("ctx.prod", c->prod, bytes);
     c->prod_cap = bytes;
     return ZKP_OK;
 }
@@ -541,6 +543,7 @@ int ensure_slot(zkp_ctx* c, zkp_ctx::HostSlot* h, int which, size_t bytes) {
     if (bytes <= h->cap[which]) return ZKP_OK;
     if (h->buf[which]) { HIPCHK(c, hipFree(h->buf[which])); h->buf[which] = nullptr; h->cap[which] = 0; }
     HIPCHK(c, hipMalloc(&h->buf[which], bytes));
+    zkp_dbg_alloc(which == 0 ? "slot.g1" : which == 1 ? "slot.g2" : which == 4 ? "slot.gt" : "slot.other", h->buf[which], bytes);
     h->cap[which] = bytes;
     return ZKP_OK;
 }
@@ -1258,14 +1261,25 @@ int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1,
 int zkp_host_alloc(size_t bytes, void** out_ptr) {
     if (!out_ptr || !bytes) return ZKP_ERR_ARG;
     *out_ptr = nullptr;
-    return hipHostMalloc(out_ptr, bytes, hipHostMallocPortable) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP;
+    const bool ok = hipHostMalloc(out_ptr, bytes, hipHostMallocPortable) == hipSuccess;
+    if (ok) zkp_dbg_alloc("host_alloc", *out_ptr, bytes);
+    return ok ? ZKP_OK : ZKP_ERR_HIP;
 }
-int zkp_host_free(void* ptr) { return !ptr || hipHostFree(ptr) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP; }
+int zkp_host_free(void* ptr) {
+    if (ptr) zkp_dbg_alloc("host_free", ptr, 0);
+    return !ptr || hipHostFree(ptr) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP;
+}
 int zkp_host_register(void* ptr, size_t bytes) {
     if (!ptr || !bytes) return ZKP_ERR_ARG;
+    // whole pages of its own only (header: pinned host memory): registrations that share a page corrupt the runtime's bookkeeping
+    if (((uintptr_t)ptr | bytes) & 4095u) return ZKP_ERR_ARG;
+    zkp_dbg_alloc("host_register", ptr, bytes);
     return hipHostRegister(ptr, bytes, hipHostRegisterPortable) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP;
 }
-int zkp_host_unregister(void* ptr) { return ptr && hipHostUnregister(ptr) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP; }
+int zkp_host_unregister(void* ptr) {
+    zkp_dbg_alloc("host_unregister", ptr, 0);
+    return ptr && hipHostUnregister(ptr) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP;
+}
 
 // measurement helper: a one-wavefront clock probe on `stream` (asynchronous); d_out receives two u64: shader clock ticks
 // and wall clock ticks over about spin_us microseconds; *wall_khz (host) is the wall clock's rate.
