@@ -126,3 +126,63 @@ def test_generated_file_is_current():
     inc = open(os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_prep_dbl.inc")).read()
     g = prepasm.generate()
     assert all(('"%s\\n\\t"' % l) in inc for l in g.lines[:60] + g.lines[-60:]), "zkp_prep_dbl.inc is not what tools/prepasm.py generates"
+
+
+def addition_model(X, Y, W, qx, qy, xP, yP):
+    th = f2sub(f2k(Y, 2), f2mul(qy, W))
+    la = f2sub(f2k(X, 2), f2mul(qx, W))
+    l2 = f2sub(f2mul(th, qx), f2mul(la, qy))
+    l1 = f2k(f2k(th, -1), xP)
+    l0 = f2k(la, yP)
+    C, D = f2mul(th, th), f2mul(la, la)
+    E, F, G = f2mul(la, D), f2mul(W, C), f2mul(f2k(X, 2), D)
+    H = f2sub(f2add(E, F), f2k(G, 2))
+    nx = f2mul(la, H)
+    ny = f2sub(f2mul(th, f2sub(G, H)), f2mul(f2k(Y, 2), E))
+    nw = f2k(f2mul(W, E), 2)
+    return nx, ny, nw, (l2, l1, l0)
+
+
+def test_addition_step_block_equals_the_formulas():
+    rng = random.Random(123)
+    g = prepasm.generate_add()
+    for trial in range(3):
+        X, Y, W = [(rng.randrange(P), rng.randrange(P)) for _ in range(3)]
+        qx, qy = (rng.randrange(P), rng.randrange(P)), (rng.randrange(P), rng.randrange(P))
+        xP, yP = rng.randrange(P), rng.randrange(P)
+        emu = asmemu.Emu(lanes=2, subst=_subst())
+        for c in range(2):
+            for base, val in ((g.X, X), (g.Y, Y), (g.W, W)):
+                for i, x in enumerate(cg.mont(val[c])):
+                    emu.v.setdefault(base + i, [None, None])[c] = x & asmemu.M32
+        nc = 5
+        emu.s[110] = 2 * nc * 64
+        emu.s[112], emu.s[113] = 0xffffffff, 0xffffffff
+        emu.s[114], emu.s[115] = 0x200000, 0
+        emu.v[1] = [0, nc * 64]
+        for v, val in ((0, (xP, xP)), (1, (yP, yP)), (2, qx), (3, qy)):
+            for lane in range(2):
+                l = cg.mont(val[lane])
+                for i in range(NL):
+                    emu.lds[(v * 4 + i // 4) * 1024 + 16 * lane + 4 * (i % 4)] = l[i] & asmemu.M32
+                for i in (14, 15):
+                    emu.lds[(v * 4 + 3) * 1024 + 16 * lane + 4 * (i % 4)] = 0
+        emu.run(g.lines)
+        assert emu.exec == 3
+        nx, ny, nw, lines = addition_model(X, Y, W, qx, qy, xP, yP)
+
+        def out(base):
+            ls = [[asmemu.s32(emu.v[base + i][c]) for i in range(NL)] for c in range(2)]
+            for l in ls:
+                assert all(abs(x) <= (1 << 27) + 16 for x in l[:NL - 1])
+                assert -0.06 * P < cg.limbs_value(l) < 1.06 * P
+            return tuple(cg.from_mont(l) for l in ls)
+
+        assert out(g.X) == nx and out(g.Y) == ny and out(g.W) == nw, trial
+        for k, want in enumerate(lines):
+            for c in range(2):
+                addr = 0x200000 + (2 * k + c) * nc * 64
+                l = [asmemu.s32(emu.mem[addr + 4 * i]) for i in range(NL)]
+                assert emu.mem[addr + 56] == 0 and emu.mem[addr + 60] == 0
+                assert abs(cg.limbs_value(l)) < 1.06 * P
+                assert cg.from_mont(l) == want[c], (trial, k, c)

@@ -41,7 +41,7 @@ class Prep:
         self.Y = v; v += 14
         self.W = v; v += 14
         self.V = []
-        for _ in range(3):
+        for _ in range(4):
             self.V.append(v); v += 14
         self.T = []
         for _ in range(3):
@@ -163,8 +163,8 @@ class Prep:
         self.prod(self.T[1], self.T[0], True, 2 * la, 2 * la)
         tail(self, dst)
 
-    def mul(self, dst, a, b, la, lb):
-        """a may be overwritten by dst; b is read once (it may be a temporary other than T0, T1, T2... see callers)"""
+    def mul_acc(self, a, b, first, la, lb):
+        """accumulate coefficient c of a b into the product set (two product blocks); b is read before the first of them"""
         T0, T1, T2 = self.T
         # T0 = a' (negated on c = 0), T2 = c ? b' : b, T1 = c ? b : b'
         self.swap(T0, a)
@@ -176,9 +176,25 @@ class Prep:
         self.lanes(0)
         self.neg(T0, T0)
         self.all_lanes()
-        self.prod(a, T2, True, la, lb)
+        self.prod(a, T2, first, la, lb)
         self.prod(T0, T1, False, la, lb)
+
+    def mul(self, dst, a, b, la, lb):
+        """a may be overwritten by dst, and so may b (it is read before the first product)"""
+        self.mul_acc(a, b, True, la, lb)
         tail(self, dst)
+
+    def prologue(self):
+        self.e("s_mov_b64 s[%d:%d], exec" % (self.sEX, self.sEX + 1))
+        for (sr, m) in ((self.sM0, 0x55555555), (self.sM1, 0xaaaaaaaa)):
+            self.e("s_mov_b32 s%d, 0x%x" % (sr, m))
+            self.e("s_mov_b32 s%d, 0x%x" % (sr + 1, m))
+        self.e("s_mov_b64 vcc, s[%d:%d]" % (self.sM1, self.sM1 + 1))
+        for i, v in enumerate(p_balanced()):
+            self.e("s_mov_b32 s%d, 0x%x" % (self.sPB + i, v & 0xffffffff))
+        self.e("v_mbcnt_lo_u32_b32 v%d, -1, 0" % self.vlds)
+        self.e("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (self.vlds, self.vlds))
+        self.e("v_lshlrev_b32 v%d, 4, v%d" % (self.vlds, self.vlds))
 
     def park_read(self, dst, v):
         """parked value v (0: xP, 1: yP) of the lane's pair -> 14 registers"""
@@ -212,18 +228,9 @@ class Prep:
 def generate(vb=6):
     g = Prep(vb)
     X, Y, W = g.X, g.Y, g.W
-    V0, V1, V2 = g.V
+    V0, V1, V2, _ = g.V
     T0, T1, T2 = g.T
-    g.e("s_mov_b64 s[%d:%d], exec" % (g.sEX, g.sEX + 1))
-    for (sr, m) in ((g.sM0, 0x55555555), (g.sM1, 0xaaaaaaaa)):
-        g.e("s_mov_b32 s%d, 0x%x" % (sr, m))
-        g.e("s_mov_b32 s%d, 0x%x" % (sr + 1, m))
-    g.e("s_mov_b64 vcc, s[%d:%d]" % (g.sM1, g.sM1 + 1))
-    for i, v in enumerate(p_balanced()):
-        g.e("s_mov_b32 s%d, 0x%x" % (g.sPB + i, v & 0xffffffff))
-    g.e("v_mbcnt_lo_u32_b32 v%d, -1, 0" % g.vlds)
-    g.e("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (g.vlds, g.vlds))
-    g.e("v_lshlrev_b32 v%d, 4, v%d" % (g.vlds, g.vlds))
+    g.prologue()
     # 1-3: B = Y^2, C = W^2, H2 = (Y + W)^2 - B - C
     g.sqr(V0, Y)
     g.sqr(V1, W)
@@ -284,8 +291,73 @@ def generate(vb=6):
     return g
 
 
+def generate_add(vb=6):
+    """the mixed addition T + Q on the same coordinates (zkp_coop.hip add_step_cln; Aranha et al. eq. (13), (14) with every quantity
+    doubled: W = 2 Z), Q = (qx, qy) parked in LDS (values 2, 3: this lane's coefficient):
+        th = 2 Y - qy W, la = 2 X - qx W (renormalised), line: c2 = th qx - la qy, c1 xP = -th xP, c0 yP = la yP,
+        C = th^2, D = la^2, E = la D, F = W C, G = 2 X D, H = E + F - 2 G, X' = la H, Y' = th (G - H) - 2 Y E, W' = 2 W E
+    Thirteen reductions (c2 and Y' are sums of two products under one reduction), seven value blocks."""
+    g = Prep(vb)
+    X, Y, W = g.X, g.Y, g.W
+    V0, V1, V2, V3 = g.V
+    T0, T1, T2 = g.T
+    QX, QY = 2, 3
+    g.prologue()
+    # th = 2 Y - qy W -> V1, la = 2 X - qx W -> V2
+    for (dst, q, src) in ((V1, QY, Y), (V2, QX, X)):
+        g.park_read(V0, q)
+        g.e("s_waitcnt lgkmcnt(0)")
+        g.mul(dst, V0, W, 1, 1)
+        g.shl(T2, src, 1)
+        g.sub(dst, T2, dst)
+        g.vred(dst)
+    # c2 = th qx - la qy under one reduction (V0 still holds qx) -> record 0 + c
+    g.mul_acc(V1, V0, True, 1, 1)
+    g.park_read(V0, QY)
+    g.e("s_waitcnt lgkmcnt(0)")
+    g.neg(V0, V0)
+    g.mul_acc(V2, V0, False, 1, 1)
+    tail(g, T2)
+    g.vred(T2)
+    g.store(T2, 0)
+    # c1 xP = -th xP -> record 2 + c; c0 yP = la yP -> record 4 + c
+    g.neg(T2, V1)
+    g.fmul(T2, T2, 0, 1)
+    g.store(T2, 2)
+    g.fmul(T2, V2, 1, 1)
+    g.store(T2, 4)
+    # D = la^2 -> V0; G = (2 X) D -> X; E = la D -> V0
+    g.sqr(V0, V2)
+    g.shl(X, X, 1)
+    g.mul(X, X, V0, 2, 1)
+    g.mul(V0, V2, V0, 1, 1)
+    # C = th^2 -> V3; F = W C -> V3
+    g.sqr(V3, V1)
+    g.mul(V3, W, V3, 1, 1)
+    # H = E + F - 2 G -> V3 (renormalised); GH = G - H -> X (renormalised)
+    g.add(V3, V3, V0)
+    g.shl(T2, X, 1)
+    g.sub(V3, V3, T2)
+    g.vred(V3)
+    g.sub(X, X, V3)
+    g.vred(X)
+    # Y' = th GH + (-2 Y) E under one reduction
+    g.mul_acc(V1, X, True, 1, 1)
+    g.shl(Y, Y, 1)
+    g.neg(Y, Y)
+    g.mul_acc(Y, V0, False, 2, 1)
+    tail(g, Y)
+    # X' = la H; W' = (2 W) E
+    g.mul(X, V2, V3, 1, 1)
+    g.shl(W, W, 1)
+    g.mul(W, W, V0, 2, 1)
+    g.e("s_waitcnt vmcnt(0)")
+    return g
+
+
 def write_inc(path, vb=6):
     g = generate(vb)
+    ga = generate_add(vb)
     n = sum(1 for l in g.lines if not l.endswith(":"))
     io = []
     for nm, base in (("x", g.X), ("y", g.Y), ("w", g.W)):
@@ -300,6 +372,12 @@ def write_inc(path, vb=6):
         f.write('    ""\n')
         f.write("// in/out: this lane's coefficient of X, Y, W (reduced values)\n")
         f.write("#define ZKP_PREP_DBL_IO(x, y, w) " + ", ".join(io) + "\n")
+        f.write("// the mixed addition step (T + Q, Q parked in LDS): %d instructions, the same operands and clobbers\n"
+                % sum(1 for l in ga.lines if not l.endswith(":")))
+        f.write("#define ZKP_PREP_ADD_ASM \\\n")
+        for l in ga.lines:
+            f.write('    "%s\\n\\t" \\\n' % l)
+        f.write('    ""\n')
         f.write("#define ZKP_PREP_DBL_CLOBBERS " + ", ".join('"v%d"' % v for v in range(g.V[0], g.vend)) + ", "
                 + ", ".join('"s%d"' % s for s in range(g.sb, g.send)) + ', "vcc", "scc", "memory"\n')
     return g, n

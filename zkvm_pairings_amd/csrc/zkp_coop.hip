@@ -1215,35 +1215,42 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
 #pragma unroll 1
     for (int b = 62; b >= 0; b--) {
 #if ZKP_PREP_ASM
-        if (CLN) {
-            // the step's three line records leave from inside the block (lanes of live pairs without an infinity); a pair with
-            // an infinity gets the neutral line from put() below
-            static_assert(NL == 14, "the generated block is for 14 limbs");
-            constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};
-            const unsigned long long smask = __ballot(live_lane && !dead);
-            const char* const sbase = (const char*)lines + (size_t)step * k * 6 * nc * 64;
-            const uint32_t voff = (uint32_t)(((size_t)j * 6 + c) * nc + check) * 64u;
-            asm volatile(ZKP_PREP_DBL_ASM
-                         : ZKP_PREP_DBL_IO(r.x.l, r.y.l, r.z.l)
-                         : [estride] "s"(2u * nc * 64u), [voff] "v"(voff), [smask] "s"(smask), [base] "s"(sbase),
-                           [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]), [p6] "s"(PL[6]),
-                           [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]), [p12] "s"(PL[12]),
-                           [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)
-                         : ZKP_PREP_DBL_CLOBBERS);
-            if (dead) { put(4, r.x); put(2, r.x); put(0, r.x); }
-        } else {
-            dbl_step(r, c, sink_l0, sink_l1, sink_l2);
-        }
+        // the step's three line records leave from inside the block (lanes of live pairs without an infinity); a pair with an
+        // infinity gets the neutral line from put() behind it
+#define ZKP_PREP_STEP_ASM(BLOCK)                                                                                                          \
+        do {                                                                                                                              \
+            constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};                                                                                  \
+            const unsigned long long smask = __ballot(live_lane && !dead);                                                                \
+            const char* const sbase = (const char*)lines + (size_t)step * k * 6 * nc * 64;                                                \
+            const uint32_t voff = (uint32_t)(((size_t)j * 6 + c) * nc + check) * 64u;                                                     \
+            asm volatile(BLOCK                                                                                                            \
+                         : ZKP_PREP_DBL_IO(r.x.l, r.y.l, r.z.l)                                                                           \
+                         : [estride] "s"(2u * nc * 64u), [voff] "v"(voff), [smask] "s"(smask), [base] "s"(sbase),                         \
+                           [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]),         \
+                           [p6] "s"(PL[6]), [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]),     \
+                           [p12] "s"(PL[12]), [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)                                                   \
+                         : ZKP_PREP_DBL_CLOBBERS);                                                                                        \
+            if (dead) { put(4, r.x); put(2, r.x); put(0, r.x); }                                                                          \
+        } while (0)
+        static_assert(NL == 14, "the generated blocks are for 14 limbs");
+        if (CLN) ZKP_PREP_STEP_ASM(ZKP_PREP_DBL_ASM); else dbl_step(r, c, sink_l0, sink_l1, sink_l2);
 #else
         if (CLN) dbl_step_cln(r, c, sink_l0, sink_l1, sink_l2); else dbl_step(r, c, sink_l0, sink_l1, sink_l2);
 #endif
         step++;
         if ((xs >> b) & 1) {
-            Fp28 l0, l1, l2;
-            if (CLN) add_step_cln(l0, l1, l2, r, park_ld(QX), park_ld(QY), c); else add_step(l0, l1, l2, r, park_ld(QX), park_ld(QY), c);
-            sink_l2(l2);
-            sink_l1(l1);
-            sink_l0(l0);
+#if ZKP_PREP_ASM
+            if (CLN) {
+                ZKP_PREP_STEP_ASM(ZKP_PREP_ADD_ASM);
+            } else
+#endif
+            {
+                Fp28 l0, l1, l2;
+                if (CLN) add_step_cln(l0, l1, l2, r, park_ld(QX), park_ld(QY), c); else add_step(l0, l1, l2, r, park_ld(QX), park_ld(QY), c);
+                sink_l2(l2);
+                sink_l1(l1);
+                sink_l0(l0);
+            }
             step++;
         }
     }
