@@ -1209,6 +1209,19 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
     auto sink_l0 = [&](const Fp28& l0) { put(4, f_mul_v(l0, park_ld(PY))); };
     auto sink_l1 = [&](const Fp28& l1) { put(2, f_mul_v(l1, park_ld(PX))); };
     auto sink_l2 = [&](Fp28 l2) { vred(l2.l); put(0, l2); };
+#if ZKP_PREP_ASM
+    // the asm steps store the lines of live pairs without an infinity only; a pair with an infinity streams the neutral line
+    // (1, 0, 0) at every step - written here, ahead of the loop, so that none of this is alive across the blocks
+    if (CLN && live_lane && dead) {
+        Fp28 o;
+        for (uint32_t st = 0; st < (uint32_t)NLINES; st++) {
+            for (uint32_t e = 0; e < 6; e += 2) {
+                if (e == 0 && c == 0) f_set(o, K28_ONE); else f_zero(o);
+                rec_store(rec(st, e + c), o);
+            }
+        }
+    }
+#endif
     // bits of |x| below its leading one: a doubling step each, an addition step after it where the bit is set
     // (the lowest bit is clear: the loop ends with the final doubling) -> 63 + 5 = 68 line records
     const uint64_t xs = 0xd201000000010000ULL;
@@ -1221,7 +1234,9 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
         do {                                                                                                                              \
             constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};                                                                                  \
             const unsigned long long smask = __ballot(live_lane && !dead);                                                                \
-            const char* const sbase = (const char*)lines + (size_t)step * k * 6 * nc * 64;                                                \
+            const uint64_t sb_ = (uint64_t)(uintptr_t)lines + (uint64_t)step * k * 6 * nc * 64;   /* wave-uniform: made scalar by hand */ \
+            const char* const sbase = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb_ >> 32)) << 32) |  \
+                                                    (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb_));                  \
             const uint32_t voff = (uint32_t)(((size_t)j * 6 + c) * nc + check) * 64u;                                                     \
             asm volatile(BLOCK                                                                                                            \
                          : ZKP_PREP_DBL_IO(r.x.l, r.y.l, r.z.l)                                                                           \
@@ -1230,7 +1245,6 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
                            [p6] "s"(PL[6]), [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]),     \
                            [p12] "s"(PL[12]), [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)                                                   \
                          : ZKP_PREP_DBL_CLOBBERS);                                                                                        \
-            if (dead) { put(4, r.x); put(2, r.x); put(0, r.x); }                                                                          \
         } while (0)
         static_assert(NL == 14, "the generated blocks are for 14 limbs");
         if (CLN) ZKP_PREP_STEP_ASM(ZKP_PREP_DBL_ASM); else dbl_step(r, c, sink_l0, sink_l1, sink_l2);
