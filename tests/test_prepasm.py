@@ -186,3 +186,29 @@ def test_addition_step_block_equals_the_formulas():
                 assert emu.mem[addr + 56] == 0 and emu.mem[addr + 60] == 0
                 assert abs(cg.limbs_value(l)) < 1.06 * P
                 assert cg.from_mont(l) == want[c], (trial, k, c)
+
+
+def test_line_stores_obey_the_lane_mask():
+    """a lane that the store mask excludes (a pair with an infinity, a lane behind the last pair) computes but stores nothing"""
+    rng = random.Random(7)
+    g = prepasm.generate()
+    X, Y, W = [(rng.randrange(P), rng.randrange(P)) for _ in range(3)]
+    emu = asmemu.Emu(lanes=2, subst=_subst())
+    for c in range(2):
+        for base, val in ((g.X, X), (g.Y, Y), (g.W, W)):
+            for i, x in enumerate(cg.mont(val[c])):
+                emu.v.setdefault(base + i, [None, None])[c] = x & asmemu.M32
+    nc = 3
+    emu.s[110] = 2 * nc * 64
+    emu.s[112], emu.s[113] = 1, 0                       # lane 0 only
+    emu.s[114], emu.s[115] = 0x300000, 0
+    emu.v[1] = [0, nc * 64]
+    for v in (0, 1):
+        l = cg.mont(rng.randrange(P))
+        for lane in range(2):
+            for i in range(16):
+                emu.lds[(v * 4 + i // 4) * 1024 + 16 * lane + 4 * (i % 4)] = (l[i] if i < NL else 0) & asmemu.M32
+    emu.run(g.lines)
+    stored = sorted({(a - 0x300000) // (nc * 64) for a in emu.mem})
+    assert stored == [0, 2, 4], stored                 # records e + 0 of lane 0; nothing of lane 1 (records 1, 3, 5)
+    assert emu.exec == 3
