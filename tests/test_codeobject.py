@@ -1,0 +1,47 @@
+"""The register facts DESIGN.md quotes, read from the code objects of the built library (no GPU needed): the hot kernels of the
+fused pairing path keep their occupancy and spill nothing.  Skipped when the library has not been built (`__graft_entry__.build()`)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "zkvm_pairings_amd", "libzkp_pairings.so")
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def _kernels():
+    data = open(SO, "rb").read()
+    out = {}
+    for i in [m.start() for m in re.finditer(b"\x7fELF\x02\x01\x01", data)][1:]:       # the embedded gfx950 code objects
+        path = "/tmp/zkp_codeobject_%d.elf" % i
+        with open(path, "wb") as f:
+            f.write(data[i:])
+        notes = subprocess.run([READELF, "--notes", path], capture_output=True, text=True).stdout
+        os.unlink(path)
+        for blk in notes.split("- .agpr_count")[1:]:
+            nm = re.search(r"\.name:\s+(\S+)", blk)
+            if nm:
+                g = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, blk).group(1))
+                out[nm.group(1)] = {"vgpr": g("vgpr_count"), "spill": g("vgpr_spill_count"), "scratch": g("private_segment_fixed_size"),
+                                    "lds": g("group_segment_fixed_size")}
+    return out
+
+
+@pytest.mark.skipif(not (os.path.exists(SO) and os.path.exists(READELF)), reason="library not built / no llvm-readelf")
+def test_hot_kernels_keep_their_registers():
+    k = _kernels()
+    find = lambda part: [v for n, v in k.items() if part in n]
+    coop = find("6k_coopILi")
+    assert len(coop) == 2 and all(v["vgpr"] <= 168 and v["spill"] == 0 and v["scratch"] == 0 for v in coop), coop      # three waves per SIMD
+    (ksq,) = find("5k_ksqE")
+    assert ksq["vgpr"] <= 168 and ksq["spill"] == 0 and ksq["scratch"] == 0, ksq
+    (prep,) = find("k_prep_linesILb1E")                                                                               # the fused paths' line steps
+    assert prep["vgpr"] <= 256 and prep["spill"] == 0 and prep["scratch"] == 0, prep
+    for name in ("k_kdec_a", "k_kdec_b"):
+        (v,) = find(name)
+        assert v["vgpr"] <= 168 and v["spill"] == 0, (name, v)
+    for name in ("k_g1_valid28", "k_g2_valid28"):
+        (v,) = find(name)
+        assert v["spill"] == 0, (name, v)
