@@ -2070,8 +2070,9 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
                       12 / WGW * coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST) <= 160 * 1024,
                   "twelve wavefronts (three per SIMD, the register bound) must fit the 160 KB of LDS of a CU");
     size_t lds_bytes = wide ? lds_wide : lds_plain;
-    static const char* pad_env = getenv("ZKP_COOP_LDS_PAD");   // occupancy experiments only
-    if (pad_env) lds_bytes += (size_t)atol(pad_env);
+    // occupancy experiments only (the VALUE is cached, not the pointer getenv returned: a later setenv may move the environment)
+    static const long lds_pad = getenv("ZKP_COOP_LDS_PAD") ? atol(getenv("ZKP_COOP_LDS_PAD")) : 0;
+    if (lds_pad > 0) lds_bytes += (size_t)lds_pad;
     unsigned blocks = (n_checks + GROUPS - 1) / GROUPS;
     if (wide)
         hipLaunchKernelGGL((k_coop<ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST>), dim3(blocks), dim3(64 * WGW), lds_bytes, s, a);
@@ -2104,8 +2105,8 @@ static hipError_t prep(CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, con
     hipStream_t s = pp->stream;
     size_t p0 = base_check * k_in;
     uint32_t n_pairs = n * g;
-    static const char* no_cln = getenv("ZKP_PREP_NO_CLN");   // A/B knob
-    if (fused && !(no_cln && atoi(no_cln)))
+    static const bool no_cln = getenv("ZKP_PREP_NO_CLN") && atoi(getenv("ZKP_PREP_NO_CLN"));   // A/B knob (value cached, not the pointer)
+    if (fused && !no_cln)
         hipLaunchKernelGGL(k_prep_lines<true>, dim3((2 * n_pairs + 63) / 64), dim3(64), 4 * 4 * 64 * sizeof(int4), s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
                            i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines);
     else

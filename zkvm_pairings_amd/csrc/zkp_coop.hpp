@@ -46,10 +46,11 @@ hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, c
 // that the address of a GPU memory fault can be matched to a buffer
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 static inline void zkp_dbg_alloc(const char* what, const void* p, size_t bytes) {
-    static const char* path = getenv("ZKP_DEBUG_ALLOC");
-    if (!path) return;
-    if (FILE* f = fopen(path, "a")) {
+    static const std::string path = getenv("ZKP_DEBUG_ALLOC") ? getenv("ZKP_DEBUG_ALLOC") : "";   // a copy: setenv may move the environment
+    if (path.empty()) return;
+    if (FILE* f = fopen(path.c_str(), "a")) {
         fprintf(f, "%s %p %zu\n", what, p, bytes);
         fclose(f);
     }
