@@ -18,8 +18,11 @@
  *   zkp_fp_op_batch                 bls12381_sys_bigint(out, op, a, b)       src/fp.rs:376,443 (op 0 = mul, 1 = add); also
  *                                   Fp::sub / neg / square / invert          src/fp.rs:307-319, 383-411, 453-455
  *   zkp_tower_op_batch              Fp2 / Fp6 / Fp12 mul, square, mul_by_014, src/fp2.rs:171-209, src/fp6.rs:188-288,
- *                                   conjugate, frobenius_map (the TRUE map)   src/fp12.rs:99-210 (:143-170 is wrong)
+ *                                   conjugate, frobenius_map (the TRUE map),  src/fp12.rs:99-210 (:143-170 is wrong)
+ *                                   invert, mul_by_nonresidue, mul_by_1 / 01  src/fp2.rs:95-102,161-168,278-296, src/fp6.rs:102-141,291-309
+ *   zkp_points_check_batch          raw points -> Fp::from_bytes, is_valid, pairing check in one call  src/fp.rs:165-207, src/g1.rs:49-62, src/g2.rs:57-69
  *   zkp_pairing_*_multi             the same pairing()/check over several GPUs from ONE host thread
+ *   zkp_comm_*, zkp_*_allreduce     one rank per GPU: the check + the path's one RCCL collective
  *
  * Wire formats (all little-endian, canonical representatives in [0,p), identical to the
  * reference's in-memory structs):
@@ -58,7 +61,8 @@ typedef enum {
     ZKP_ERR_NO_DEVICE = -2,    /* no usable HIP device */
     ZKP_ERR_HIP = -3,          /* a HIP runtime call failed; see zkp_last_error */
     ZKP_ERR_NONCANONICAL = -4, /* an input limb array is >= p (validation mode) */
-    ZKP_ERR_OOM = -5
+    ZKP_ERR_OOM = -5,
+    ZKP_ERR_COMM = -6          /* an RCCL call failed or the context has no communicator; see zkp_last_error */
 } zkp_status;
 
 /* zkp_fp_op_batch: the operation in bits 0..3, the limb core in bit 4.  0 and 1 are the op numbers of the zkVM precompile
@@ -90,8 +94,18 @@ typedef enum {
     ZKP_TOWER_FP12_CYCLOTOMIC_SQUARE = 10,  /* Granger-Scott; input in the cyclotomic subgroup */
     ZKP_TOWER_FP12_CYCLOTOMIC_POW2K = 11,   /* g^(2^repeat), 1 <= repeat <= 64: compressed squarings + decompression
                                                (the building block of the final exponentiation's x-power chains) */
-    ZKP_TOWER_FP12_CYCLOTOMIC_DECOMPRESS = 12 /* Karabina decompression: c0.c0 and c1.c1 of the result are recomputed from
+    ZKP_TOWER_FP12_CYCLOTOMIC_DECOMPRESS = 12, /* Karabina decompression: c0.c0 and c1.c1 of the result are recomputed from
                                                the other four Fp2 coefficients of the record (cooperative family only) */
+    /* the rest of the tower functions SURVEY.md 8(a) names, as direct hooks.  The inversions return the ZERO record for a
+     * non-invertible (zero) input, where the reference returns None. */
+    ZKP_TOWER_FP2_INVERT = 13,              /* src/fp2.rs:278-296 */
+    ZKP_TOWER_FP2_MUL_BY_NONRESIDUE = 14,   /* (c0 - c1) + (c0 + c1) u, src/fp2.rs:161-168 */
+    ZKP_TOWER_FP2_MUL_FP = 15,              /* Mul<&Fp> for Fp2, src/fp2.rs:95-102: b = the Fp value in the first 6 u64 of its record */
+    ZKP_TOWER_FP6_MUL_BY_1 = 16,            /* src/fp6.rs:102-108: b = c1 (Fp2) in the first 12 u64 */
+    ZKP_TOWER_FP6_MUL_BY_01 = 17,           /* src/fp6.rs:110-127: b = c0 | c1 in the first 24 u64 */
+    ZKP_TOWER_FP6_MUL_BY_NONRESIDUE = 18,   /* * v, src/fp6.rs:130-141 */
+    ZKP_TOWER_FP6_INVERT = 19,              /* src/fp6.rs:291-309 */
+    ZKP_TOWER_FP12_INVERT = 20              /* src/fp12.rs:186-190 */
 } zkp_tower_op;
 
 /* which Miller-loop/final-exp kernel family the context uses */
@@ -193,6 +207,32 @@ int zkp_g1_mul_batch_dev(zkp_ctx* ctx, const void* d_base, size_t base_stride, c
 int zkp_g2_mul_batch_dev(zkp_ctx* ctx, const void* d_base, size_t base_stride, const void* d_scalars, size_t n,
                          void* d_out, void* d_out_inf, void* stream);
 
+/* the uncompressed point codec on resident buffers (same formats and status bytes as zkp_g1/g2_decode_batch above) */
+int zkp_g1_decode_batch_dev(zkp_ctx* ctx, const void* d_bytes, size_t n, void* d_out_g1, void* d_out_inf, void* d_status, void* stream);
+int zkp_g2_decode_batch_dev(zkp_ctx* ctx, const void* d_bytes, size_t n, void* d_out_g2, void* d_out_inf, void* d_status, void* stream);
+int zkp_g1_encode_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_inf /* may be NULL */, size_t n, void* d_out_bytes, void* stream);
+int zkp_g2_encode_batch_dev(zkp_ctx* ctx, const void* d_g2, const void* d_inf /* may be NULL */, size_t n, void* d_out_bytes, void* stream);
+
+/* ---- BASELINE config 5 as ONE call: raw uncompressed points -> decode -> is_valid -> pairing check ------------------------------
+ * n_checks groups of k consecutive (G1, G2) pairs given as byte strings (96 B per G1 point, 192 B per G2 point, the codec's format).
+ * Every point is decoded (Fp::from_bytes with the correct range check, src/fp.rs:165-207) and validated (G1Affine::is_valid
+ * src/g1.rs:49-62, G2Affine::is_valid src/g2.rs:57-69); st1[i] / st2[i] (n_checks * k bytes each, may be NULL) receive a
+ * zkp_point_status.  ok[c] = (every point of check c is valid AND prod_j e(P_cj, Q_cj) == Gt::identity()); *all_ok = AND over the
+ * checks (each may be NULL).  A point that is not valid takes no part in the Miller loop (no arithmetic on garbage); its check
+ * fails.  Decoded points, infinity flags and intermediate status bytes stay in the context's workspace in HBM: the host flavour
+ * moves only the byte strings up and the status / ok bytes down. */
+typedef enum {
+    ZKP_POINT_OK = 0,               /* a point of the r-torsion subgroup, or a well-formed infinity */
+    ZKP_POINT_NONCANONICAL = 1,     /* a coordinate >= p */
+    ZKP_POINT_MALFORMED = 2,        /* compressed / sort flag set, or an infinity flag over non-zero bytes */
+    ZKP_POINT_NOT_ON_CURVE = 3,     /* "Point is not on curve", src/g1.rs:54-56 */
+    ZKP_POINT_NOT_IN_SUBGROUP = 4   /* "Point is not torsion free", src/g1.rs:57-59 */
+} zkp_point_status;
+int zkp_points_check_batch(zkp_ctx* ctx, const uint8_t* g1_bytes, const uint8_t* g2_bytes, size_t n_checks, size_t k, uint8_t* st1,
+                           uint8_t* st2, uint8_t* ok, int* all_ok);
+int zkp_points_check_batch_dev(zkp_ctx* ctx, const void* d_g1_bytes, const void* d_g2_bytes, size_t n_checks, size_t k, void* d_st1,
+                               void* d_st2, void* d_ok, void* d_all_ok, void* stream);
+
 /* validation mode (zkp_set_validate) on the device-pointer entry points: the range check of the inputs runs on the caller's
  * stream and ORs into a word inside the context - no host synchronisation in the *_dev call itself.  This call waits for
  * `stream`, reports whether any *_dev call since the last query saw a field element >= p (*bad = 1; the results of such a
@@ -213,6 +253,35 @@ int zkp_pairing_check_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_
 int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1,
                             const uint8_t* inf2, size_t n, uint64_t* out_gt, uint8_t* ok, int* all_ok);
 
+/* ---- one process (rank) per GPU: the path's ONE collective behind the C ABI ------------------------------------
+ * librccl is linked into libzkp_pairings.so; a Rust / C host needs nothing outside this header to finish a sharded check:
+ *     rank 0: zkp_comm_unique_id(id)            -> hand the 128 bytes to every rank by the host's own means (file, socket, MPI)
+ *     every rank: zkp_comm_init_rank(ctx, nranks, rank, id)        (collective: returns when all ranks have joined)
+ *     every rank: zkp_pairing_check_batch_allreduce(ctx, <its contiguous block of the checks>, ok, &all_ok)
+ * = zkp_pairing_check_batch on the rank's block, then ONE ncclAllReduce(count = 1, ncclInt32, ncclMin) of the AND flag on the
+ * context's stream (RCCL has no bitwise AND; MIN of {0,1} is AND): *all_ok is the AND over ALL ranks' checks, ok[] stays
+ * per-rank.  Nothing else crosses xGMI.  A context holds at most one communicator; zkp_free destroys it.  No reference
+ * counterpart (the reference is a single-threaded host crate); the torch.distributed flavour of the same step is
+ * zkvm_pairings_amd/dist.py. */
+#define ZKP_COMM_ID_BYTES 128
+int zkp_comm_unique_id(void* out_id /* ZKP_COMM_ID_BYTES */);
+int zkp_comm_init_rank(zkp_ctx* ctx, int nranks, int rank, const void* unique_id /* ZKP_COMM_ID_BYTES */);
+int zkp_comm_destroy(zkp_ctx* ctx);
+/* *nranks = 0 when the context has no communicator */
+int zkp_comm_info(const zkp_ctx* ctx, int* nranks, int* rank);
+/* in-place AND of one int32 {0,1} flag in device memory over the ranks, asynchronous on `stream` (the building block) */
+int zkp_and_allreduce_dev(zkp_ctx* ctx, void* d_flag, void* stream);
+int zkp_pairing_check_batch_allreduce(zkp_ctx* ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
+                                      size_t n_checks, size_t k, uint8_t* ok /* may be NULL */, int* all_ok);
+/* d_all_ok (one int32, required) receives the AND over all ranks; asynchronous on `stream` */
+int zkp_pairing_check_batch_allreduce_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1, const void* d_inf2,
+                                          size_t n_checks, size_t k, void* d_ok, void* d_all_ok, void* stream);
+/* SURVEY.md 8e variant, ONE product check over the whole sharded batch: this rank's zkp_miller_product, ONE ncclAllGather of
+ * 576 B per rank, the product of the gathered values and ONE final exponentiation on every rank (identical results):
+ * *is_one = (prod over ALL ranks' pairs of e(P_i, Q_i) == Gt::identity()); out_gt (72 u64) may be NULL. */
+int zkp_pairing_product_check_allgather(zkp_ctx* ctx, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
+                                        size_t n, uint64_t* out_gt, int* is_one);
+
 /* ---- pinned host memory for the host-pointer entry points ("H2D/D2H per GPU straight from pinned host
  * memory on its own stream") ------------------------------------------------------------------------------------------
  * The host-pointer entry points copy with hipMemcpyAsync on their own streams.  From PAGEABLE memory such a copy stages
@@ -221,7 +290,8 @@ int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1,
  * overlaps the kernels and the other contexts' copies.  zkp_host_alloc returns page-locked memory usable with every
  * context / GPU of the process (hipHostMallocPortable); zkp_host_register page-locks an existing allocation in place
  * (hipHostRegister: slow, of the order of 1 ms per 4 MB - do it once for a buffer that is reused, not per call).  The
- * registered range must consist of WHOLE PAGES of its own: ptr and bytes multiples of the page size (4096), i.e. memory
+ * registered range must consist of WHOLE PAGES of its own: ptr and bytes multiples of the page size (sysconf(_SC_PAGESIZE),
+ * 4096 on the GPU boxes; zkp_host_unregister(NULL) is ZKP_ERR_ARG), i.e. memory
  * from posix_memalign / aligned_alloc / mmap, not a slice of the malloc heap - the driver locks and maps pages, and two
  * registrations that share a page (two neighbouring heap arrays) left the HIP runtime with a stale entry after the
  * unregistration: a later copy from a reused heap address then went to the GPU as a DMA from an unmapped page (a GPU

@@ -1,6 +1,6 @@
 //! UNTESTED - the build image has no Rust toolchain; this crate has never been compiled.
 //!
-//! `zkp-pairings-sys`: raw bindings to include/zkp_pairings.h (ABI version 2) plus safe batch wrappers over slices of
+//! `zkp-pairings-sys`: raw bindings to include/zkp_pairings.h (ABI version 3) plus safe batch wrappers over slices of
 //! limbs.  Wire formats are the zkvm-pairings crate's own in-memory layouts: `Fp.0: [u64; 6]` canonical little-endian
 //! limbs (reference src/fp.rs:24), Fp12 in declaration order (src/fp12.rs:13-16), points as coordinate arrays plus a
 //! parallel infinity byte array.  The crate-level API (`pairing`, `multi_miller_loop`, `final_exponentiation`, `Gt`)
@@ -18,6 +18,15 @@ pub const ZKP_ERR_NO_DEVICE: c_int = -2;
 pub const ZKP_ERR_HIP: c_int = -3;
 pub const ZKP_ERR_NONCANONICAL: c_int = -4;
 pub const ZKP_ERR_OOM: c_int = -5;
+pub const ZKP_ERR_COMM: c_int = -6;
+/// bytes of the communicator id `zkp_comm_unique_id` produces (RCCL's ncclUniqueId)
+pub const ZKP_COMM_ID_BYTES: usize = 128;
+/// zkp_point_status of `zkp_points_check_batch`
+pub const ZKP_POINT_OK: u8 = 0;
+pub const ZKP_POINT_NONCANONICAL: u8 = 1;
+pub const ZKP_POINT_MALFORMED: u8 = 2;
+pub const ZKP_POINT_NOT_ON_CURVE: u8 = 3;
+pub const ZKP_POINT_NOT_IN_SUBGROUP: u8 = 4;
 
 /// zkp_fp_op: 0 and 1 are the zkVM precompile's op numbers (reference src/fp.rs:376,443)
 pub const ZKP_FP_MUL: c_int = 0;
@@ -101,6 +110,33 @@ extern "C" {
                                 d_out: *mut c_void, d_out_inf: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn zkp_g2_mul_batch_dev(ctx: *mut ZkpCtx, d_base: *const c_void, base_stride: usize, d_scalars: *const c_void, n: usize,
                                 d_out: *mut c_void, d_out_inf: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn zkp_g1_decode_batch_dev(ctx: *mut ZkpCtx, d_bytes: *const c_void, n: usize, d_out_g1: *mut c_void, d_out_inf: *mut c_void,
+                                   d_status: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn zkp_g2_decode_batch_dev(ctx: *mut ZkpCtx, d_bytes: *const c_void, n: usize, d_out_g2: *mut c_void, d_out_inf: *mut c_void,
+                                   d_status: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn zkp_g1_encode_batch_dev(ctx: *mut ZkpCtx, d_g1: *const c_void, d_inf: *const c_void, n: usize, d_out_bytes: *mut c_void,
+                                   stream: *mut c_void) -> c_int;
+    pub fn zkp_g2_encode_batch_dev(ctx: *mut ZkpCtx, d_g2: *const c_void, d_inf: *const c_void, n: usize, d_out_bytes: *mut c_void,
+                                   stream: *mut c_void) -> c_int;
+    /// BASELINE config 5 in one call: raw uncompressed points -> Fp::from_bytes, is_valid, pairing check (status bytes + flags)
+    pub fn zkp_points_check_batch(ctx: *mut ZkpCtx, g1_bytes: *const u8, g2_bytes: *const u8, n_checks: usize, k: usize, st1: *mut u8,
+                                  st2: *mut u8, ok: *mut u8, all_ok: *mut c_int) -> c_int;
+    pub fn zkp_points_check_batch_dev(ctx: *mut ZkpCtx, d_g1_bytes: *const c_void, d_g2_bytes: *const c_void, n_checks: usize, k: usize,
+                                      d_st1: *mut c_void, d_st2: *mut c_void, d_ok: *mut c_void, d_all_ok: *mut c_void,
+                                      stream: *mut c_void) -> c_int;
+    /// one rank per GPU: the path's ONE collective (RCCL all-reduce(MIN) of the AND flag) behind the ABI
+    pub fn zkp_comm_unique_id(out_id: *mut c_void) -> c_int;
+    pub fn zkp_comm_init_rank(ctx: *mut ZkpCtx, nranks: c_int, rank: c_int, unique_id: *const c_void) -> c_int;
+    pub fn zkp_comm_destroy(ctx: *mut ZkpCtx) -> c_int;
+    pub fn zkp_comm_info(ctx: *const ZkpCtx, nranks: *mut c_int, rank: *mut c_int) -> c_int;
+    pub fn zkp_and_allreduce_dev(ctx: *mut ZkpCtx, d_flag: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn zkp_pairing_check_batch_allreduce(ctx: *mut ZkpCtx, g1: *const u64, g2: *const u64, inf1: *const u8, inf2: *const u8,
+                                             n_checks: usize, k: usize, ok: *mut u8, all_ok: *mut c_int) -> c_int;
+    pub fn zkp_pairing_check_batch_allreduce_dev(ctx: *mut ZkpCtx, d_g1: *const c_void, d_g2: *const c_void, d_inf1: *const c_void,
+                                                 d_inf2: *const c_void, n_checks: usize, k: usize, d_ok: *mut c_void,
+                                                 d_all_ok: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn zkp_pairing_product_check_allgather(ctx: *mut ZkpCtx, g1: *const u64, g2: *const u64, inf1: *const u8, inf2: *const u8,
+                                               n: usize, out_gt: *mut u64, is_one: *mut c_int) -> c_int;
     pub fn zkp_take_validation_status_dev(ctx: *mut ZkpCtx, stream: *mut c_void, bad: *mut c_int) -> c_int;
     pub fn zkp_clock_probe_dev(ctx: *mut ZkpCtx, stream: *mut c_void, spin_us: c_uint, d_out: *mut c_void, wall_khz: *mut c_int) -> c_int;
     pub fn zkp_time_pairing_dev(ctx: *mut ZkpCtx, d_g1: *const c_void, d_g2: *const c_void, n: usize, d_out_gt: *mut c_void,
@@ -118,16 +154,33 @@ pub struct Error {
 /// Page-locked host memory (`zkp_host_alloc`): the container to keep point / Gt arrays in when they are handed to the
 /// host-pointer entry points - their copies are then DMAs that overlap the kernels (and, in the multi-GPU call, the other
 /// GPUs' copies) instead of blocking staged copies.  Derefs to a slice; usable with every engine of the process.
-pub struct PinnedVec<T: Copy> {
+pub struct PinnedVec<T: Pod> {
     ptr: *mut T,
     len: usize,
 }
-unsafe impl<T: Copy + Send> Send for PinnedVec<T> {}
+/// The element types a `PinnedVec` may hold: plain integers, for which the all-zero bit pattern is a value (a `Copy` bound alone
+/// would admit references and `NonZero*`, whose zeroed form is undefined behaviour reachable from safe code).  Sealed.
+pub trait Pod: Copy + sealed::Sealed {}
+mod sealed {
+    pub trait Sealed {}
+    impl Sealed for u8 {}
+    impl Sealed for u32 {}
+    impl Sealed for u64 {}
+    impl Sealed for i32 {}
+}
+impl Pod for u8 {}
+impl Pod for u32 {}
+impl Pod for u64 {}
+impl Pod for i32 {}
+unsafe impl<T: Pod + Send> Send for PinnedVec<T> {}
 
-impl<T: Copy> PinnedVec<T> {
+impl<T: Pod> PinnedVec<T> {
     pub fn zeroed(len: usize) -> Result<Self, Error> {
         let mut p: *mut c_void = core::ptr::null_mut();
-        let bytes = core::cmp::max(1, len * core::mem::size_of::<T>());
+        let bytes = match len.checked_mul(core::mem::size_of::<T>()) {
+            Some(b) => core::cmp::max(1, b),
+            None => return Err(Error { status: ZKP_ERR_ARG, detail: format!("PinnedVec of {len} elements overflows usize") }),
+        };
         let rc = unsafe { zkp_host_alloc(bytes, &mut p) };
         if rc != ZKP_OK {
             return Err(Error { status: rc, detail: format!("zkp_host_alloc({bytes} bytes)") });
@@ -141,18 +194,18 @@ impl<T: Copy> PinnedVec<T> {
         Ok(v)
     }
 }
-impl<T: Copy> core::ops::Deref for PinnedVec<T> {
+impl<T: Pod> core::ops::Deref for PinnedVec<T> {
     type Target = [T];
     fn deref(&self) -> &[T] {
         unsafe { core::slice::from_raw_parts(self.ptr, self.len) }
     }
 }
-impl<T: Copy> core::ops::DerefMut for PinnedVec<T> {
+impl<T: Pod> core::ops::DerefMut for PinnedVec<T> {
     fn deref_mut(&mut self) -> &mut [T] {
         unsafe { core::slice::from_raw_parts_mut(self.ptr, self.len) }
     }
 }
-impl<T: Copy> Drop for PinnedVec<T> {
+impl<T: Pod> Drop for PinnedVec<T> {
     fn drop(&mut self) {
         unsafe { zkp_host_free(self.ptr as *mut c_void) };
     }
@@ -276,6 +329,63 @@ impl Engine {
         let rc = unsafe { zkp_g2_is_valid_batch(self.0, g2.as_ptr(), opt_ptr(inf), st.len(), st.as_mut_ptr()) };
         if rc == ZKP_OK { Ok(st) } else { Err(self.err(rc)) }
     }
+
+    /// BASELINE config 5 in one call: `g1_bytes` n x 96, `g2_bytes` n x 192 uncompressed big-endian points, groups of k pairs.
+    /// Returns (status per G1 point, status per G2 point [`ZKP_POINT_*`], per-check flags, AND of all): a check passes when all
+    /// its points decode, are valid (reference `is_valid`, src/g1.rs:49-62, src/g2.rs:57-69) and its pairing product is the identity.
+    #[allow(clippy::type_complexity)]
+    pub fn points_check_batch(&mut self, g1_bytes: &[u8], g2_bytes: &[u8], k: usize) -> Result<(Vec<u8>, Vec<u8>, Vec<u8>, bool), Error> {
+        if g1_bytes.len() % 96 != 0 || g2_bytes.len() != 2 * g1_bytes.len() || k == 0 || (g1_bytes.len() / 96) % k != 0 {
+            return Err(Error { status: ZKP_ERR_ARG, detail: "byte string lengths / k".into() });
+        }
+        let n = g1_bytes.len() / 96;
+        let (mut st1, mut st2, mut ok) = (vec![0u8; n], vec![0u8; n], vec![0u8; n / k]);
+        let mut all: c_int = 1;
+        let rc = unsafe {
+            zkp_points_check_batch(self.0, g1_bytes.as_ptr(), g2_bytes.as_ptr(), n / k, k, st1.as_mut_ptr(), st2.as_mut_ptr(), ok.as_mut_ptr(), &mut all)
+        };
+        if rc == ZKP_OK { Ok((st1, st2, ok, all != 0)) } else { Err(self.err(rc)) }
+    }
+
+    /// Join the job's communicator (one rank per GPU; `id` from `comm_unique_id()` on rank 0, handed to every rank by the host's
+    /// own means).  Collective: returns when all `nranks` ranks have called it.
+    pub fn comm_init_rank(&mut self, nranks: i32, rank: i32, id: &[u8; ZKP_COMM_ID_BYTES]) -> Result<(), Error> {
+        let rc = unsafe { zkp_comm_init_rank(self.0, nranks, rank, id.as_ptr() as *const c_void) };
+        if rc == ZKP_OK { Ok(()) } else { Err(self.err(rc)) }
+    }
+
+    /// This rank's contiguous block of a sharded check + the path's ONE collective (RCCL all-reduce(MIN) of the AND flag):
+    /// returns (this rank's per-check flags, AND over ALL ranks' checks).  Every rank must call it once per global check.
+    pub fn pairing_check_batch_allreduce(&mut self, g1: &[u64], g2: &[u64], inf1: Option<&[u8]>, inf2: Option<&[u8]>, k: usize)
+                                         -> Result<(Vec<u8>, bool), Error> {
+        let n = Self::pairs(g1, g2, inf1, inf2)?;
+        if k == 0 || n % k != 0 {
+            return Err(Error { status: ZKP_ERR_ARG, detail: "the number of pairs is not a multiple of k".into() });
+        }
+        let mut ok = vec![0u8; n / k];
+        let mut all: c_int = 1;
+        let rc = unsafe {
+            zkp_pairing_check_batch_allreduce(self.0, g1.as_ptr(), g2.as_ptr(), opt_ptr(inf1), opt_ptr(inf2), n / k, k, ok.as_mut_ptr(), &mut all)
+        };
+        if rc == ZKP_OK { Ok((ok, all != 0)) } else { Err(self.err(rc)) }
+    }
+
+    /// ONE product check over the whole sharded batch: this rank's Miller product, one all-gather of 576 B per rank, one final
+    /// exponentiation; every rank gets the same (Gt, is_one)
+    pub fn pairing_product_check_allgather(&mut self, g1: &[u64], g2: &[u64], inf1: Option<&[u8]>, inf2: Option<&[u8]>) -> Result<([u64; 72], bool), Error> {
+        let n = Self::pairs(g1, g2, inf1, inf2)?;
+        let mut gt = [0u64; 72];
+        let mut one: c_int = 0;
+        let rc = unsafe { zkp_pairing_product_check_allgather(self.0, g1.as_ptr(), g2.as_ptr(), opt_ptr(inf1), opt_ptr(inf2), n, gt.as_mut_ptr(), &mut one) };
+        if rc == ZKP_OK { Ok((gt, one != 0)) } else { Err(self.err(rc)) }
+    }
+}
+
+/// the 128-byte communicator id (rank 0 makes it; every rank passes the same bytes to `Engine::comm_init_rank`)
+pub fn comm_unique_id() -> Result<[u8; ZKP_COMM_ID_BYTES], Error> {
+    let mut id = [0u8; ZKP_COMM_ID_BYTES];
+    let rc = unsafe { zkp_comm_unique_id(id.as_mut_ptr() as *mut c_void) };
+    if rc == ZKP_OK { Ok(id) } else { Err(Error { status: rc, detail: "zkp_comm_unique_id".into() }) }
 }
 
 impl Drop for Engine {

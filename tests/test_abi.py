@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), "libzkp_pairings.so does not export %s" % n
         assert n in _lib.SIGNATURES, "python binding table lacks %s" % n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.zkp_abi_version() == 2
+    assert lib.zkp_abi_version() == 3
 
 
 def test_rust_and_c_bindings_list_the_same_symbols():
@@ -33,6 +33,97 @@ def test_rust_and_c_bindings_list_the_same_symbols():
     with open(os.path.join(ROOT, "integration", "rust", "src", "lib.rs")) as f:
         rust = sorted(set(re.findall(r"pub fn (zkp_[a-z0-9_]+)\s*\(", f.read())))
     assert rust == _declared_symbols()
+
+
+def _split_params(txt):
+    txt = txt.strip()
+    return [] if txt in ("", "void") else [p.strip() for p in txt.split(",")]
+
+
+def _c_signatures():
+    """name -> (return kind, [parameter kinds]) from the header; kinds: ptr / size / int / void"""
+    with open(os.path.join(ROOT, "include", "zkp_pairings.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+
+    def kind(t):
+        if "*" in t:
+            return "ptr"
+        if "size_t" in t:
+            return "size"
+        if re.search(r"\b(int|unsigned|uint32_t)\b", t):
+            return "int"
+        assert t.strip() == "void", t
+        return "void"
+
+    out = {}
+    for ret, name, params in re.findall(r"([A-Za-z_][A-Za-z0-9_ ]*?[ \*]+)(zkp_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        out[name] = (kind(ret), [kind(p) for p in _split_params(params)])
+    return out
+
+
+def _rust_signatures():
+    with open(os.path.join(ROOT, "integration", "rust", "src", "lib.rs")) as f:
+        text = re.sub(r"//[^\n]*", "", f.read())
+
+    def kind(t):
+        t = t.strip()
+        if t.startswith("*"):
+            return "ptr"
+        if t == "usize":
+            return "size"
+        assert t in ("c_int", "c_uint", "u32", "i32"), t
+        return "int"
+
+    out = {}
+    for name, params, ret in re.findall(r"pub fn (zkp_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", text):
+        ps = [kind(p.split(":", 1)[1]) for p in _split_params(params)]
+        out[name] = ("void" if not ret.strip() else kind(ret), ps)
+    return out
+
+
+def test_rust_and_ctypes_signatures_match_the_header():
+    """arity and the kind of every parameter (pointer / size_t / int) of the Rust `extern "C"` block and of the ctypes table
+    against the prototypes of include/zkp_pairings.h - not just the names: a binding with a swapped or missing size argument
+    corrupts memory at the first call, and the Rust side cannot be compiled here"""
+    import ctypes as ct
+    from zkvm_pairings_amd import _lib
+    c = _c_signatures()
+    assert sorted(c) == _declared_symbols()
+    rust = _rust_signatures()
+    assert sorted(rust) == sorted(c)
+    for name, sig in c.items():
+        assert rust[name] == sig, (name, "rust", rust[name], "header", sig)
+
+    def ckind(t):
+        if t is None:
+            return "void"
+        if t is ct.c_size_t:
+            return "size"
+        if t in (ct.c_int, ct.c_uint, ct.c_uint32):
+            return "int"
+        assert t in (ct.c_void_p, ct.c_char_p) or issubclass(t, ct._Pointer), t
+        return "ptr"
+
+    for name, (res, args) in _lib.SIGNATURES.items():
+        assert (ckind(res), [ckind(x) for x in args]) == c[name], (name, "ctypes")
+
+
+def test_plain_c_consumers_compile_and_link(tmp_path):
+    """integration/c/*.c against the header and the library (build + link only: they need a GPU to run; -m gpu runs them)"""
+    import glob
+    import subprocess
+    libdir = os.path.join(ROOT, "zkvm_pairings_amd")
+    for src in sorted(glob.glob(os.path.join(ROOT, "integration", "c", "*.c"))):
+        exe = str(tmp_path / os.path.basename(src)[:-2])
+        subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", libdir, "-lzkp_pairings",
+                               "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+
+
+def test_library_links_rccl_for_the_one_collective():
+    """the AND-reduce lives behind the C ABI - the library itself depends on librccl"""
+    import subprocess
+    out = subprocess.run(["readelf", "-d", os.path.join(ROOT, "zkvm_pairings_amd", "libzkp_pairings.so")], capture_output=True, text=True).stdout
+    assert "librccl.so" in out
 
 
 def test_gt_identity_and_strerror():

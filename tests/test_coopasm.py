@@ -29,9 +29,12 @@ def test_generated_constants_match_the_step_programs():
     assert coopasm.P_BLS == cg.P
     assert coopasm.p_balanced() == list(cg.P_BAL)
     assert (coopasm.VRED_C, coopasm.VRED_SHIFT_IN, coopasm.VRED_SHIFT_OUT) == (cg.VRED_C, cg.VRED_SHIFT_IN, cg.VRED_SHIFT_OUT)
-    inc = open(os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_coop_mulacc.inc")).read()
-    g = coopasm.generate_ksq()
-    assert all(('"%s\\n\\t"' % l) in inc for l in g.lines[:50] + g.lines[-50:]), "zkp_coop_mulacc.inc is not what tools/coopasm.py generates"
+    # byte for byte: the emulator tests of this file run what the generator emits NOW, the compiler what is checked in
+    import tempfile
+    with tempfile.NamedTemporaryFile("r", suffix=".inc") as tf:
+        coopasm.write_inc(tf.name)
+        assert open(os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_coop_mulacc.inc")).read() == open(tf.name).read(), \
+            "zkp_coop_mulacc.inc is not what tools/coopasm.py generates: run tools/coopasm.py"
 
 
 def test_ksq_body_equals_the_model_of_a_compressed_squaring():

@@ -184,6 +184,39 @@ def test_tower_op_programs_match_model():
     assert cg.Emu(state=st).run(cg.prog_tower_from_snap().steps).wire_out == m.f12_flat_ints(h)
 
 
+def test_remaining_tower_programs_match_model():
+    """round 4: mul_by_nonresidue, Fp2 x Fp, Fp6::mul_by_1 / mul_by_01 and the three inversions (program A, the batched
+    inversion's value, program B) against the big-int model; a zero input ends as the zero record"""
+    g = m.SplitMix64(99)
+    rnd = lambda: [g.below(m.P) for _ in range(12)]
+    a, b = rnd(), rnd()
+    pad = lambda v: list(v) + [0] * (12 - len(v))
+    f2 = lambda v: (v[0], v[1])
+    f6 = lambda v: ((v[0], v[1]), (v[2], v[3]), (v[4], v[5]))
+    flat6 = lambda t: [c for pr in t for c in pr]
+    z = (0, 0)
+    run = lambda op, x, y=None: cg.Emu(wire_in=x, wire_in2=y).run(cg.prog_tower2(op).steps).wire_out
+    assert run("fp2_nr", pad(a[:2])) == pad(m.f2_mul_xi(f2(a)))
+    assert run("fp2_mulfp", pad(a[:2]), pad(b[:1])) == pad([a[0] * b[0] % m.P, a[1] * b[0] % m.P])
+    assert run("fp6_by1", pad(a[:6]), pad(b[:2])) == pad(flat6(m.f6_mul(f6(a), (z, f2(b), z))))
+    assert run("fp6_by01", pad(a[:6]), pad(b[:4])) == pad(flat6(m.f6_mul(f6(a), (f2(b), (b[2], b[3]), z))))
+    assert run("fp6_nr", pad(a[:6])) == pad(flat6(m.f6_mul(f6(a), (z, (1, 0), z))))
+
+    def inv(which, x):
+        prog_a = cg.prog_fexp_a(True) if which == "fp12" else cg.prog_tower_inv_a(which)
+        ea = cg.Emu(wire_in=x).run(prog_a.steps)
+        nn = cg.from_mont(ea.state[cg.ST_N])
+        ea.state[cg.ST_NINV] = cg.mont(m.fp_inv(nn) if nn else 0)      # k_batch_inv: 0 gives 0
+        return cg.Emu(state=ea.state).run(cg.prog_tower_inv_b(which).steps).wire_out
+
+    assert inv("fp2", pad(a[:2])) == pad(m.f2_inv(f2(a)))
+    assert inv("fp6", pad(a[:6])) == pad(flat6(m.f6_inv(f6(a))))
+    assert inv("fp12", a) == m.f12_flat_ints(m.f12_inv(m.f12_from_flat_ints(a)))
+    for w in ("fp2", "fp6", "fp12"):
+        assert inv(w, [0] * 12) == [0] * 12
+        assert cg.PROGRAMS["tw_%s_inv_b" % w]().peak <= cg.LDS_SLOTS
+
+
 def test_program_encoding_is_consistent():
     for name, mk in cg.PROGRAMS.items():
         b = mk()

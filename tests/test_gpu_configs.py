@@ -69,6 +69,144 @@ def test_config5_raw_points_2p20(eng):
         fn = o.g1_is_valid if which == "g1" else o.g2_is_valid
         assert [fn(p, int(i)) for p, i in zip(pts, inf)] == st.tolist()
     assert r["pairing_checks_all_one"]
+    # round 4: the same flow as ONE call (zkp_points_check_batch / _dev): raw bytes -> decode -> is_valid -> pairing check on 2^20
+    # two-pair checks built from the same byte strings; every status byte and every ok byte equals the expectation the three-call
+    # flow above established, the resident flavour gives the same bytes, a batch of good checks sets the AND flag
+    assert r["one_call_status_equal"] and r["one_call_ok_equal"] and r["one_call_dev_equal"], r["one_call_sha256"]
+    assert r["one_call_all_ok"] == 0 and r["one_call_n_ok"] > (1 << 19) and r["one_call_good_subset_all_ok"]
+
+
+def test_points_check_small_cases_vs_oracle(eng):
+    """zkp_points_check_batch on hand-made byte strings: every point class in either position, k = 1 and k = 3, against the
+    oracle's from_bytes / is_valid / pairing check; empty batch; an infinity pairs to the identity"""
+    from zkvm_pairings_amd import configs, synthetic
+    n = 42
+    raw1, cls1 = configs.raw_points(eng, n, 1, 77)
+    raw2, cls2 = configs.raw_points(eng, n, 2, 78)
+    pool1, pc1 = configs.raw_points(eng, 4096, 1, 5)
+    pool2, pc2 = configs.raw_points(eng, 4096, 2, 6)
+    for c in range(1, len(configs.CLASSES)):          # every class on either side, whatever the seed of the 42 drew
+        raw1[c - 1] = pool1[np.flatnonzero(pc1 == c)[0]]
+        raw2[5 + c] = pool2[np.flatnonzero(pc2 == c)[0]]
+
+    def oracle_status(raw, which):
+        nfp = 2 if which == 1 else 4
+        out = []
+        for row in raw:
+            flags = row[0] & 0xE0
+            if flags & 0xA0:
+                out.append((2, None, 0))
+                continue
+            if flags & 0x40:
+                rest = row.copy()
+                rest[0] &= 0x1F
+                out.append((2, None, 0) if rest.any() else (0, None, 1))
+                continue
+            fes = []
+            body = row.copy()
+            for e in range(nfp):
+                fe = o.fp_from_bytes_be(bytes(body[48 * e: 48 * e + 48]))
+                fes.append(fe)
+            if any(f is None for f in fes):
+                out.append((1, None, 0))
+                continue
+            pt = np.concatenate(fes if which == 1 else [fes[1], fes[0], fes[3], fes[2]])
+            v = (o.g1_is_valid if which == 1 else o.g2_is_valid)(pt, 0)
+            out.append((v + 2 if v else 0, pt, 0))
+        return out
+
+    o1, o2 = oracle_status(raw1, 1), oracle_status(raw2, 2)
+    for k in (1, 3):
+        s1, s2, ok, allok = eng.points_check(raw1, raw2, k)
+        assert s1.tolist() == [x[0] for x in o1] and s2.tolist() == [x[0] for x in o2], k
+        want = []
+        for c in range(n // k):
+            idx = range(c * k, c * k + k)
+            if any(o1[i][0] or o2[i][0] for i in idx):
+                want.append(0)
+                continue
+            live = [i for i in idx if not (o1[i][2] or o2[i][2])]
+            if not live:
+                want.append(1)
+                continue
+            g1 = np.stack([o1[i][1] for i in live])
+            g2 = np.stack([o2[i][1] for i in live])
+            want.append(int(o.pairing_check_batch(g1, g2, 1, len(live))[0]))
+        assert ok.tolist() == want and allok == all(want), k
+    s1, s2, ok, allok = eng.points_check(raw1[:0], raw2[:0], 1)
+    assert s1.size == 0 and ok.size == 0 and allok
+    # cancelling pair from the generators: ok, AND flag true
+    P = synthetic.G1_GENERATOR.reshape(1, 12)
+    B1 = np.concatenate([configs.to_bytes(P, 1), configs.to_bytes(configs.negate_g1(eng, P), 1)])
+    B2 = np.repeat(configs.to_bytes(synthetic.G2_GENERATOR.reshape(1, 24), 2), 2, axis=0)
+    s1, s2, ok, allok = eng.points_check(B1, B2, 2)
+    assert not s1.any() and not s2.any() and ok.tolist() == [1] and allok
+
+
+def test_codec_on_resident_tensors(eng):
+    """zkp_g1/g2_decode_batch_dev / encode_batch_dev: the same bytes and points as the host-pointer codec, aligned and unaligned views"""
+    import torch
+    from zkvm_pairings_amd import configs
+    for which in (1, 2):
+        raw, cls = configs.raw_points(eng, 3000, which, 1234 + which)
+        pts, inf, st = eng.decode_points(raw, which)
+        t = torch.from_numpy(raw).cuda()
+        dp, di, ds = eng.decode_points_dev(t, which)
+        assert np.array_equal(dp.cpu().numpy().view(np.uint64), pts) and np.array_equal(di.cpu().numpy(), inf) and np.array_equal(ds.cpu().numpy(), st)
+        # an unaligned view of the same bytes takes the byte-wise kernel: same result
+        pad = torch.empty(raw.size + 3, dtype=torch.uint8, device="cuda")
+        pad[3:] = t.reshape(-1)
+        up, ui, us = eng.decode_points_dev(pad[3:], which)
+        assert torch.equal(up, dp) and torch.equal(ui, di) and torch.equal(us, ds)
+        good = np.flatnonzero(st == 0)
+        enc = eng.encode_points_dev(dp[torch.from_numpy(good).cuda()].contiguous(), which, di[torch.from_numpy(good).cuda()].contiguous())
+        assert np.array_equal(enc.cpu().numpy(), raw[good])
+        assert eng.encode_points(pts[good], which, inf[good]) == raw[good].tobytes()
+
+
+def test_rccl_and_reduce_behind_the_c_abi(tmp_path):
+    """integration/c/zkp_comm.c: a plain-C rank runs its block of a sharded check and the path's one collective through
+    include/zkp_pairings.h alone (zkp_comm_unique_id / zkp_comm_init_rank / zkp_pairing_check_batch_allreduce /
+    zkp_pairing_product_check_allgather) - here as a ONE-rank communicator, which is what one GPU allows (RCCL refuses two
+    ranks on one device); and the same entry points from Python on device tensors"""
+    exe = str(tmp_path / "zkp_comm")
+    libdir = os.path.join(ROOT, "zkvm_pairings_amd")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "integration", "c", "zkp_comm.c"),
+                           "-L", libdir, "-lzkp_pairings", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe, "1", "0", str(tmp_path / "comm.id"), "0"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "rank 0 of 1: RCCL AND-reduce behind the C ABI ok" in out.stdout
+    code = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+import zkvm_pairings_amd as z
+from zkvm_pairings_amd import synthetic, configs
+eng = z.PairingEngine(0)
+assert eng.comm_info() == (0, 0)
+eng.comm_init_rank(1, 0, z.PairingEngine.comm_unique_id())
+assert eng.comm_info() == (1, 0)
+g1, g2, _, _ = synthetic.random_pairs(eng, 64, seed=3)
+G1 = np.stack([g1, configs.negate_g1(eng, g1)], axis=1).reshape(-1, 12)
+G2 = np.repeat(g2, 2, axis=0)
+ok, allok = eng.pairing_check_allreduce(G1, G2, 2)
+assert ok.all() and allok is True
+ok, allok = eng.pairing_check_allreduce(g1, g2, 1)
+assert not ok.any() and allok is False
+t1, t2 = torch.from_numpy(G1.view(np.int64)).cuda(), torch.from_numpy(G2.view(np.int64)).cuda()
+ok, flag = eng.pairing_check_allreduce(t1, t2, 2)
+torch.cuda.synchronize()
+assert bool(ok.all().item()) and int(flag.item()) == 1
+f = torch.zeros(1, dtype=torch.int32, device="cuda"); eng.and_allreduce(f); assert int(f.item()) == 0
+gt, one = eng.pairing_product_check_allgather(G1, G2)
+assert one and np.array_equal(gt, eng.gt_identity())
+gt2, one2 = eng.pairing_product_check(g1, g2)
+gt3, one3 = eng.pairing_product_check_allgather(g1, g2)
+assert np.array_equal(gt2, gt3) and one2 == one3 == False
+eng.comm_destroy(); assert eng.comm_info() == (0, 0)
+eng.close(); print("ABI COMM OK")
+'''
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "ABI COMM OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
 
 def test_pairing_over_several_contexts_from_c(tmp_path):

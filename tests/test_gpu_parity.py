@@ -148,6 +148,55 @@ def test_tower_ops_direct_vs_oracle(keng, ref_kats):
     assert keng.tower_op("fp12_mul", a12[:0], b12[:0]).shape == (0, 72)
 
 
+def test_remaining_tower_functions_direct_vs_oracle(keng, ref_kats):
+    """The tower functions SURVEY 8(a) names that round 3 reached only inside larger programs, as direct hooks of
+    zkp_tower_op_batch on both kernel families: Fp2::invert (src/fp2.rs:278-296), mul_by_nonresidue (:161-168), Mul<&Fp> (:95-102);
+    Fp6::mul_by_1 / mul_by_01 / mul_by_nonresidue / invert (src/fp6.rs:102-141, 291-309); Fp12::invert (src/fp12.rs:186-190).
+    Zero inputs included: the reference returns None, the hook the zero record (and the oracle reports not-invertible)."""
+    n = 24
+    H = lambda s: int(s, 16)
+    a12 = _rnd_records(41, n, 12)
+    a6, b6 = _rnd_records(42, n, 6), _rnd_records(43, n, 6)
+    a2, b2 = _rnd_records(44, n, 2), _rnd_records(45, n, 2)
+    for j, key in enumerate(("a", "b", "c")):
+        a12[j] = np.concatenate([o.to_limbs(H(x) % m.P) for x in ref_kats["fp12_arith"][key]])
+        a6[j, :36] = np.concatenate([o.to_limbs(H(x) % m.P) for x in ref_kats["fp6_arith"][key]])
+    # non-invertible and degenerate inputs: zero, one, an element of the base field, a value with a zero half
+    for arr, w in ((a2, 12), (a6, 36), (a12, 72)):
+        arr[3] = 0
+        arr[4] = 0
+        arr[4, 0] = 1
+        arr[5, 6:] = 0
+        arr[6, : w // 2] = 0
+    b2[3] = 0
+    b6[3] = 0
+
+    def check(op, a, b, width, fn):
+        got = keng.tower_op(op, a, b)
+        for i in range(n):
+            want = np.zeros(72, dtype=np.uint64)
+            r = fn(i)
+            if r is not None:        # None: the oracle's "not invertible" (the reference's None) -> the zero record
+                want[:width] = r
+            assert np.array_equal(got[i], want), (op, i)
+
+    check("fp2_invert", a2, None, 12, lambda i: o.fp2_invert(a2[i, :12]))
+    check("fp2_mul_by_nonresidue", a2, None, 12, lambda i: o.fp2_mul_by_nonresidue(a2[i, :12]))
+    check("fp2_mul_fp", a2, b2, 12, lambda i: np.concatenate([o.fp_mul(a2[i, :6], b2[i, :6]), o.fp_mul(a2[i, 6:12], b2[i, :6])]))
+    check("fp6_mul_by_1", a6, b6, 36, lambda i: o.fp6_mul_by_1(a6[i, :36], b6[i, :12]))
+    check("fp6_mul_by_01", a6, b6, 36, lambda i: o.fp6_mul_by_01(a6[i, :36], b6[i, :12], b6[i, 12:24]))
+    check("fp6_mul_by_nonresidue", a6, None, 36, lambda i: o.fp6_mul_by_nonresidue(a6[i, :36]))
+    check("fp6_invert", a6, None, 36, lambda i: o.fp6_invert(a6[i, :36]))
+    check("fp12_invert", a12, None, 72, lambda i: o.fp12_invert(a12[i]))
+    assert o.fp2_invert(a2[3, :12]) is None and o.fp6_invert(a6[3, :36]) is None and o.fp12_invert(a12[3]) is None
+    # x * x^-1 == 1 through the hooks themselves
+    inv = keng.tower_op("fp12_invert", a12)
+    prod = keng.tower_op("fp12_mul", a12, inv)
+    for i in range(n):
+        if i != 3:
+            assert np.array_equal(prod[i], keng.gt_identity()), i
+
+
 def _decompress_model(z2, z3, z4, z5):
     """Karabina decompression in this tower's coordinates with Python integers (the formulas k_kdec_a / k_kdec_b implement;
     0 / 0 := 0) -> (z0, z1)"""

@@ -123,9 +123,12 @@ def test_doubling_step_block_equals_the_formulas():
 
 
 def test_generated_file_is_current():
-    inc = open(os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_prep_dbl.inc")).read()
-    g = prepasm.generate()
-    assert all(('"%s\\n\\t"' % l) in inc for l in g.lines[:60] + g.lines[-60:]), "zkp_prep_dbl.inc is not what tools/prepasm.py generates"
+    """byte for byte: the emulator tests of this file run what the generator emits NOW, the compiler what is checked in"""
+    import tempfile
+    with tempfile.NamedTemporaryFile("r", suffix=".inc") as tf:
+        prepasm.write_inc(tf.name)
+        assert open(os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_prep_dbl.inc")).read() == open(tf.name).read(), \
+            "zkp_prep_dbl.inc is not what tools/prepasm.py generates: run tools/prepasm.py"
 
 
 def addition_model(X, Y, W, qx, qy, xP, yP):

@@ -1539,6 +1539,124 @@ def prog_tower(op):
     return out_wire(r)
 
 
+# ---- the rest of SURVEY 8(a)'s tower functions as direct hooks (round 4): sparse Fp6 products, the nonresidue maps, Fp2 x Fp, and
+# the three inversions.  An inversion is a plan of three steps: program A (wire -> state: the norm chain down to ONE Fp value in
+# ST_N), the batched inversion kernel (ST_N -> ST_NINV; 0 gives 0), program B (state -> wire).  A non-invertible input (zero)
+# therefore gives the zero record where the reference returns None (src/fp2.rs:278-296, src/fp6.rs:291-309, src/fp12.rs:186-190).
+TOWER_OPS2 = ("fp2_nr", "fp2_mulfp", "fp6_by1", "fp6_by01", "fp6_nr")
+
+
+def _tower_out_wire(b, v, t):
+    raw1 = Lin.of(CONST_SLOT["RAW_ONE"])
+    b.mulacc([{"dst": t[i], "bil": Bil([(v.lin(i), raw1, 1)])} for i in range(12)])
+    b.gstore(K_WIRE, [(t[i], i) for i in range(12)])
+    return b
+
+
+def prog_tower2(op):
+    """Fp2::mul_by_nonresidue src/fp2.rs:161-168, Mul<&Fp> for Fp2 :95-102 (b = the Fp value in the first 6 u64 of its record),
+    Fp6::mul_by_1 src/fp6.rs:102-108 (b = c1), Fp6::mul_by_01 :110-127 (b = c0 | c1), Fp6::mul_by_nonresidue :130-141"""
+    b = Builder()
+    a = load_input(b, True)
+    bb = load_input(b, True, wire_kind=K_WIRE2) if op in ("fp2_mulfp", "fp6_by1", "fp6_by01") else None
+    t = bb.slots if bb else b.alloc(12)
+    d = a.slots
+    if op == "fp2_nr":
+        parts = list(l2_xi(a.fp2(0)))
+    elif op == "fp6_nr":
+        parts = [c for pr in l6_mul_v(a.fp6(0)) for c in pr]
+    else:
+        parts = None
+    if parts is not None:
+        b.lin([(t[i], parts[i] if i < len(parts) else Lin.of(ZERO)) for i in range(12)])
+        return _tower_out_wire(b, V12(t), d)
+    if op == "fp2_mulfp":
+        s = bb.lin(0)
+        bil = [Bil([(a.lin(0), s, 1)]), Bil([(a.lin(1), s, 1)])]
+    else:
+        x = a.fp6(0)
+        z = (Lin(), Lin())
+        y = (z, bb.fp2(0), z) if op == "fp6_by1" else (bb.fp2(0), bb.fp2(1), z)
+        bil = [c for pr in b6_mul(y, x) for c in pr]       # the sparse operand on the A side: merge_terms drops its zero forms
+    b.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(bil)])
+    b.lin([(d[i], Lin.of(ZERO)) for i in range(len(bil), 12)])
+    return _tower_out_wire(b, V12(d), t)
+
+
+def _fp6_inv_a(b, t):
+    """t: 3-tuple of Lin pairs (an Fp6 value in slots).  Cofactors C (ST_C), N in Fp2 (ST_NC), n = |N|^2 (ST_N) - the chain of
+    prog_fexp_a behind its t = a0^2 - v a1^2"""
+    C0 = b2_sub(b2_mul(t[0], t[0]), b2_xi(b2_mul(t[1], t[2])))
+    C1 = b2_sub(b2_xi(b2_mul(t[2], t[2])), b2_mul(t[0], t[1]))
+    C2 = b2_sub(b2_mul(t[1], t[1]), b2_mul(t[0], t[2]))
+    cs = b.alloc(6)
+    b.mulacc([{"dst": cs[2 * j + c], "bil": (C0, C1, C2)[j][c]} for j in range(3) for c in range(2)])
+    C = tuple(lin2(cs[2 * j], cs[2 * j + 1]) for j in range(3))
+    Nb = b2_add(b2_xi(b2_add(b2_mul(t[1], C[2]), b2_mul(t[2], C[1]))), b2_mul(t[0], C[0]))
+    ns = b.alloc(2)
+    b.mulacc([{"dst": ns[c], "bil": Nb[c]} for c in range(2)])
+    n1 = b.alloc(1)
+    b.mulacc([{"dst": n1[0], "bil": Bil([(Lin.of(ns[0]), Lin.of(ns[0]), 1), (Lin.of(ns[1]), Lin.of(ns[1]), 1)])}])
+    b.gstore(K_STATE, [(cs[i], ST_C + i) for i in range(6)] + [(ns[i], ST_NC + i) for i in range(2)] + [(n1[0], ST_N)])
+
+
+def _fp6_inv_b(b):
+    """-> slots of t^-1 = C N^-1 from ST_C, ST_NC, ST_NINV (the opening of prog_fexp_c)"""
+    st = b.alloc(9)
+    b.gload(K_STATE, [(st[i], ST_C + i) for i in range(6)] + [(st[6 + i], ST_NC + i) for i in range(2)] + [(st[8], ST_NINV)])
+    C = tuple(lin2(st[2 * j], st[2 * j + 1]) for j in range(3))
+    N = lin2(st[6], st[7])
+    ninv = Lin.of(st[8])
+    ni = b.alloc(2)
+    b.mulacc([{"dst": ni[0], "bil": Bil([(N[0], ninv, 1)])}, {"dst": ni[1], "bil": Bil([(N[1], ninv, -1)])}])
+    NI = lin2(ni[0], ni[1])
+    ti = b.alloc(6)
+    b.mulacc([{"dst": ti[2 * j + c], "bil": b2_mul(C[j], NI)[c]} for j in range(3) for c in range(2)])
+    b.release(st)
+    b.release(ni)
+    return ti
+
+
+def prog_tower_inv_a(which):
+    """program A of Fp2::invert / Fp6::invert (Fp12::invert uses fexp_a_wire as it stands)"""
+    b = Builder()
+    a = load_input(b, True)
+    if which == "fp2":
+        n1 = b.alloc(1)
+        b.mulacc([{"dst": n1[0], "bil": Bil([(a.lin(0), a.lin(0), 1), (a.lin(1), a.lin(1), 1)])}])
+        b.gstore(K_STATE, [(a.slots[i], ST_NC + i) for i in range(2)] + [(n1[0], ST_N)])
+    else:
+        _fp6_inv_a(b, a.fp6(0))
+    return b
+
+
+def prog_tower_inv_b(which):
+    """program B: fp2: (a0 ninv, -a1 ninv); fp6: C N^-1; fp12: conj(f) t^-1 = (a0 t^-1, -a1 t^-1) with f from ST_F"""
+    b = Builder()
+    if which == "fp2":
+        st = b.alloc(3)
+        b.gload(K_STATE, [(st[i], ST_NC + i) for i in range(2)] + [(st[2], ST_NINV)])
+        r = b.alloc(12)
+        b.mulacc([{"dst": r[0], "bil": Bil([(Lin.of(st[0]), Lin.of(st[2]), 1)])}, {"dst": r[1], "bil": Bil([(Lin.of(st[1]), Lin.of(st[2]), -1)])}])
+        b.lin([(r[i], Lin.of(ZERO)) for i in range(2, 12)])
+        b.release(st)
+        return _tower_out_wire(b, V12(r), b.alloc(12))
+    ti = _fp6_inv_b(b)
+    if which == "fp6":
+        r = b.alloc(12)
+        b.lin([(r[i], Lin.of(ti[i]) if i < 6 else Lin.of(ZERO)) for i in range(12)])
+        b.release(ti)
+        return _tower_out_wire(b, V12(r), b.alloc(12))
+    TI = tuple(lin2(ti[2 * j], ti[2 * j + 1]) for j in range(3))
+    f = V12(b.alloc(12))
+    b.gload(K_STATE, [(f.slots[i], ST_F + i) for i in range(12)])
+    fc = f.conj()
+    # in place: every lane reads f's slots before the step stores (one MULACC step)
+    b.mulacc([{"dst": f.slots[i], "bil": bl} for i, bl in enumerate(flatten12(b6_mul(TI, fc.fp6(0)), b6_mul(TI, fc.fp6(1))))])
+    b.release(ti)
+    return _tower_out_wire(b, V12(f.slots), b.alloc(12))
+
+
 def prog_tower_to_state(base=0):
     """wire record -> Montgomery limbs in state elements base..base+11 (0: input of a compressed squaring run; ST_SNAP:
     a snapshot whose z0, z1 the decompression kernels are to recover)"""
@@ -1662,6 +1780,12 @@ PROGRAMS = {
 
 for _op in TOWER_OPS:
     PROGRAMS["tw_" + _op] = (lambda op=_op: prog_tower(op))
+for _op in TOWER_OPS2:
+    PROGRAMS["tw_" + _op] = (lambda op=_op: prog_tower2(op))
+for _w in ("fp2", "fp6"):
+    PROGRAMS["tw_%s_inv_a" % _w] = (lambda w=_w: prog_tower_inv_a(w))
+for _w in ("fp2", "fp6", "fp12"):
+    PROGRAMS["tw_%s_inv_b" % _w] = (lambda w=_w: prog_tower_inv_b(w))
 PROGRAMS["tw_to_state"] = prog_tower_to_state
 PROGRAMS["tw_to_snap"] = lambda: prog_tower_to_state(ST_SNAP)
 PROGRAMS["tw_from_snap"] = prog_tower_from_snap

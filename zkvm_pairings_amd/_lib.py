@@ -55,6 +55,20 @@ SIGNATURES = {
     "zkp_g2_is_valid_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp]),
     "zkp_g1_mul_batch_dev": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp, c_vp, c_vp]),
     "zkp_g2_mul_batch_dev": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "zkp_g1_decode_batch_dev": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
+    "zkp_g2_decode_batch_dev": (c_int, [c_vp, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
+    "zkp_g1_encode_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "zkp_g2_encode_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "zkp_points_check_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, c_vp, c_vp, ctypes.POINTER(c_int)]),
+    "zkp_points_check_batch_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "zkp_comm_unique_id": (c_int, [c_vp]),
+    "zkp_comm_init_rank": (c_int, [c_vp, c_int, c_int, c_vp]),
+    "zkp_comm_destroy": (c_int, [c_vp]),
+    "zkp_comm_info": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "zkp_and_allreduce_dev": (c_int, [c_vp, c_vp, c_vp]),
+    "zkp_pairing_check_batch_allreduce": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, ctypes.POINTER(c_int)]),
+    "zkp_pairing_check_batch_allreduce_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, c_vp, c_vp]),
+    "zkp_pairing_product_check_allgather": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, ctypes.POINTER(c_int)]),
     "zkp_take_validation_status_dev": (c_int, [c_vp, c_vp, ctypes.POINTER(c_int)]),
     "zkp_pairing_check_batch_multi": (c_int, [ctypes.POINTER(c_vp), c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, ctypes.POINTER(c_int)]),
     "zkp_pairing_batch_multi": (c_int, [ctypes.POINTER(c_vp), c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.POINTER(c_int)]),

@@ -208,7 +208,7 @@ def raw_points(eng, n, which, seed):
 
 def run_config5(eng, n, seed=0x5EED5):
     r = {}
-    decoded = {}
+    decoded, raws = {}, {}
     for which, name in ((1, "g1"), (2, "g2")):
         raw, cls = raw_points(eng, n, which, seed + which)
         pts, inf, st = eng.decode_points(raw, which)
@@ -223,6 +223,43 @@ def run_config5(eng, n, seed=0x5EED5):
         r[name + "_sample"] = (pts[pick], inf[pick], val[pick])
         r[name + "_sha256_status"] = hashlib.sha256(val.tobytes()).hexdigest()
         decoded[which] = (pts, inf, val, st, cls)
+        raws[which] = raw
+    # ---- the same through ONE call (round 4, zkp_points_check_batch): check c = the two pairs (P_c, Q_c), (-P_c, Q_c) given as raw
+    # bytes.  Expected by construction: the status byte of every point (decode status, else is_valid status + 2) and
+    # ok[c] = both points of c valid (an infinity pairs to the identity), for EVERY check.
+    comb = lambda st, val: np.where(st != 0, st, np.where(val != 0, val + 2, 0)).astype(np.uint8)
+    pts1, inf1, val1, dec1, cls1 = decoded[1]
+    pts2, inf2, val2, dec2, cls2 = decoded[2]
+    raw1 = raws[1]
+    neg1 = raw1.copy()
+    dec_ok = (dec1 == 0) & (inf1 == 0)
+    neg1[dec_ok] = to_bytes(negate_g1(eng, np.ascontiguousarray(pts1[dec_ok])), 1)
+    B1 = np.stack([raw1, neg1], axis=1).reshape(2 * n, 96)
+    B2 = np.repeat(raws[2], 2, axis=0)
+    want1, want2 = np.repeat(comb(dec1, val1), 2), np.repeat(comb(dec2, val2), 2)
+    want_ok = ((comb(dec1, val1) == 0) & (comb(dec2, val2) == 0)).astype(np.uint8)
+    s1, s2, okb, allok = eng.points_check(B1, B2, 2)
+    r["one_call_status_equal"] = bool(np.array_equal(s1, want1) and np.array_equal(s2, want2))
+    r["one_call_ok_equal"] = bool(np.array_equal(okb, want_ok))
+    r["one_call_all_ok"] = int(allok)
+    r["one_call_n_ok"] = int(want_ok.sum())
+    r["one_call_sha256"] = hashlib.sha256(s1.tobytes() + s2.tobytes() + okb.tobytes()).hexdigest()
+    # device-resident flavour on the same bytes: identical bytes out; and a batch of good checks only: AND flag true
+    import torch
+    dev = torch.device("cuda", eng.device)
+    t1, t2 = torch.from_numpy(B1).to(dev), torch.from_numpy(B2).to(dev)
+    d1 = torch.empty(2 * n, dtype=torch.uint8, device=dev)
+    d2 = torch.empty(2 * n, dtype=torch.uint8, device=dev)
+    dok = torch.empty(n, dtype=torch.uint8, device=dev)
+    dflag = torch.empty(1, dtype=torch.int32, device=dev)
+    eng.points_check(t1, t2, 2, d1, d2, dok, dflag)
+    r["one_call_dev_equal"] = bool(np.array_equal(d1.cpu().numpy(), s1) and np.array_equal(d2.cpu().numpy(), s2) and
+                                   np.array_equal(dok.cpu().numpy(), okb) and int(dflag.item()) == int(allok))
+    goodc = np.flatnonzero(want_ok)[: 1 << 14]
+    sel = (2 * goodc[:, None] + np.arange(2)[None, :]).reshape(-1)
+    _, _, okg, allg = eng.points_check(B1[sel], B2[sel], 2)
+    r["one_call_good_subset_all_ok"] = bool(okg.all() and allg)
+    del t1, t2, d1, d2, dok
     # the pairing leg on points that passed both checks: e(P,Q) e(-P,Q) == 1 on a 2^16 subset
     good = np.flatnonzero((decoded[1][4] == 0) & (decoded[2][4] == 0))[: 1 << 16]
     p1, p2 = decoded[1][0][good], decoded[2][0][good]

@@ -2314,12 +2314,39 @@ hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, ui
     static const int progs[11] = {ZKP_PROG_TW_FP2_MUL, ZKP_PROG_TW_FP2_SQR, ZKP_PROG_TW_FP6_MUL, ZKP_PROG_TW_FP6_SQR, ZKP_PROG_TW_FP12_FROB,
                                   ZKP_PROG_TW_FP12_MUL, ZKP_PROG_TW_FP12_SQR, ZKP_PROG_TW_FP12_014, ZKP_PROG_TW_FP12_FROB, ZKP_PROG_TW_FP12_CONJ,
                                   ZKP_PROG_TW_CYC_SQR};
-    if (op < 0 || op > 12 || n > 0x3fffffffu) return hipErrorInvalidValue;
+    if (op < 0 || op > 20 || n > 0x3fffffffu) return hipErrorInvalidValue;
     hipError_t e;
     for (size_t base = 0; base < n; base += d->chunk) {
         const uint32_t m = (uint32_t)(n - base < d->chunk ? n - base : d->chunk);
         CoopPipe v = d->pipe[0];
         v.stream = s;
+        if (op >= 13) {
+            // round 4: the remaining tower functions of SURVEY 8(a).  One program for the sparse products and the nonresidue maps;
+            // an inversion is program A (wire -> state, the norm chain down to ONE Fp value), the batched inversion kernel (0 gives
+            // 0: a non-invertible input ends as the zero record), program B (state -> wire) - for Fp12 exactly the route
+            // final_exponentiation() takes (fexp_a, k_batch_inv, the opening of fexp_c)
+            int one = -1, pa = -1, pb = -1;
+            switch (op) {
+                case 13: pa = ZKP_PROG_TW_FP2_INV_A; pb = ZKP_PROG_TW_FP2_INV_B; break;
+                case 14: one = ZKP_PROG_TW_FP2_NR; break;
+                case 15: one = ZKP_PROG_TW_FP2_MULFP; break;
+                case 16: one = ZKP_PROG_TW_FP6_BY1; break;
+                case 17: one = ZKP_PROG_TW_FP6_BY01; break;
+                case 18: one = ZKP_PROG_TW_FP6_NR; break;
+                case 19: pa = ZKP_PROG_TW_FP6_INV_A; pb = ZKP_PROG_TW_FP6_INV_B; break;
+                default: pa = ZKP_PROG_FEXP_A_WIRE; pb = ZKP_PROG_TW_FP12_INV_B; break;
+            }
+            if (one >= 0) {
+                if ((e = run_prog(d, &v, one, m, m, 1, ab + 72 * base, out + 72 * base, nullptr, nullptr, 0, (uint32_t)n)) != hipSuccess) return e;
+                continue;
+            }
+            if ((e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, (size_t)ST_SIZE * d->chunk * 64)) != hipSuccess) return e;
+            v.state = d->pipe[0].state;
+            if ((e = run_prog(d, &v, pa, m, m, 1, ab + 72 * base, nullptr, nullptr, nullptr)) != hipSuccess) return e;
+            if ((e = run_inv(d, s, v.state, m, m, ZKP_COOP_ST_N, ZKP_COOP_ST_NINV, 1)) != hipSuccess) return e;
+            if ((e = run_prog(d, &v, pb, m, m, 1, nullptr, out + 72 * base, nullptr, nullptr)) != hipSuccess) return e;
+            continue;
+        }
         if (op <= 10) {
             if ((e = run_prog(d, &v, progs[op], m, m, 1, ab + 72 * base, out + 72 * base, nullptr, nullptr, 0, (uint32_t)n)) != hipSuccess) return e;
             // ZKP_TOWER_FP6_FROBENIUS runs the Fp12 program; the Fp6 result is its c0 half, the rest of the record is zero whatever

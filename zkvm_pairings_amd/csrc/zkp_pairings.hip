@@ -5,10 +5,12 @@
 // There is no CPU fallback anywhere in this file: every entry point either runs HIP kernels or
 // returns a negative status.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <new>
 #include <string>
 
@@ -281,6 +283,15 @@ __global__ void __launch_bounds__(TPB) k_tower_op(int op, const uint64_t* a, con
         case ZKP_TOWER_FP12_FROBENIUS: fp12_frob(&r, &x); break;
         case ZKP_TOWER_FP12_CONJUGATE: fp12_conj(&r, &x); break;
         case ZKP_TOWER_FP12_CYCLOTOMIC_SQUARE: fp12_cyclotomic_square(&r, &x); break;
+        // a non-invertible input leaves the zero record (the reference returns None)
+        case ZKP_TOWER_FP2_INVERT: if (!fp2_inv(&r.c0.c0, &x.c0.c0)) fp2_zero(&r.c0.c0); break;
+        case ZKP_TOWER_FP2_MUL_BY_NONRESIDUE: fp2_mul_nr(&r.c0.c0, &x.c0.c0); break;
+        case ZKP_TOWER_FP2_MUL_FP: fp2_mul_fp(&r.c0.c0, &x.c0.c0, &y.c0.c0.c0); break;
+        case ZKP_TOWER_FP6_MUL_BY_1: fp6_mul_by_1(&r.c0, &x.c0, &y.c0.c0); break;
+        case ZKP_TOWER_FP6_MUL_BY_01: fp6_mul_by_01(&r.c0, &x.c0, &y.c0.c0, &y.c0.c1); break;
+        case ZKP_TOWER_FP6_MUL_BY_NONRESIDUE: fp6_mul_nr(&r.c0, &x.c0); break;
+        case ZKP_TOWER_FP6_INVERT: if (!fp6_inv(&r.c0, &x.c0)) fp6_zero(&r.c0); break;
+        case ZKP_TOWER_FP12_INVERT: if (!fp12_inv(&r, &x)) { fp6_zero(&r.c0); fp6_zero(&r.c1); } break;
         default:
             r = x;
             for (uint32_t k = 0; k < repeat; k++) { Fp12 t; fp12_cyclotomic_square(&t, &r); r = t; }
@@ -291,6 +302,16 @@ __global__ void __launch_bounds__(TPB) k_tower_op(int op, const uint64_t* a, con
 
 // ---- uncompressed byte codec: nfp big-endian 48-byte field elements per point (2 for G1, 4 for G2).
 // G2 stores c1 before c0, so element e of the byte string is wire element (e ^ 1) when nfp == 4.
+// ALIGNED: the byte strings start on an 8-byte boundary (96 and 192 are multiples of 8): a big-endian word is one 64-bit load + a
+// byte swap instead of eight byte loads.
+template <bool ALIGNED>
+__device__ __forceinline__ uint64_t be64_load(const uint8_t* p) {
+    if (ALIGNED) return __builtin_bswap64(*reinterpret_cast<const uint64_t*>(p));
+    uint64_t v = 0;
+    for (int b = 0; b < 8; b++) v = (v << 8) | p[b];
+    return v;
+}
+template <bool ALIGNED>
 __global__ void k_decode(const uint8_t* bytes, size_t n, int nfp, uint64_t* out, uint8_t* out_inf, uint8_t* status) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -300,15 +321,14 @@ __global__ void k_decode(const uint8_t* bytes, size_t n, int nfp, uint64_t* out,
     if (flags & 0xa0) st = 2;                       // compressed or sort flag: not an uncompressed point
     if (!st && (flags & 0x40)) {
         inf = 1;
-        uint8_t any = src[0] & 0x1f;
-        for (int b = 1; b < 48 * nfp; b++) any |= src[b];
+        uint64_t any = be64_load<ALIGNED>(src) & 0x1fffffffffffffffULL;
+        for (int w = 1; w < 6 * nfp; w++) any |= be64_load<ALIGNED>(src + 8 * w);
         if (any) st = 2;
     }
     for (int e = 0; e < nfp; e++) {
         uint64_t limbs[6];
         for (int w = 0; w < 6; w++) {
-            uint64_t v = 0;
-            for (int b = 0; b < 8; b++) v = (v << 8) | src[48 * e + 8 * w + b];
+            uint64_t v = be64_load<ALIGNED>(src + 48 * e + 8 * w);
             if (e == 0 && w == 0) v &= 0x1fffffffffffffffULL;   // strip the flag bits
             limbs[5 - w] = v;
         }
@@ -320,6 +340,7 @@ __global__ void k_decode(const uint8_t* bytes, size_t n, int nfp, uint64_t* out,
     out_inf[i] = inf && !st;
     status[i] = st;
 }
+template <bool ALIGNED>
 __global__ void k_encode(const uint64_t* pts, const uint8_t* inf, size_t n, int nfp, uint8_t* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -329,10 +350,36 @@ __global__ void k_encode(const uint64_t* pts, const uint8_t* inf, size_t n, int 
         const int we = nfp == 4 ? (e ^ 1) : e;
         for (int w = 0; w < 6; w++) {
             uint64_t v = is_inf ? 0 : pts[(i * nfp + we) * 6 + (5 - w)];
-            for (int b = 0; b < 8; b++) dst[48 * e + 8 * w + b] = (uint8_t)(v >> (56 - 8 * b));
+            if (is_inf && e == 0 && w == 0) v = 0x4000000000000000ULL;
+            if (ALIGNED) {
+                *reinterpret_cast<uint64_t*>(dst + 48 * e + 8 * w) = __builtin_bswap64(v);
+            } else {
+                for (int b = 0; b < 8; b++) dst[48 * e + 8 * w + b] = (uint8_t)(v >> (56 - 8 * b));
+            }
         }
     }
-    if (is_inf) dst[0] |= 0x40;
+}
+
+// zkp_points_check_batch: one status byte per point from the decode status (0 ok, 1 coordinate >= p, 2 malformed) and the is_valid
+// status (0, 1 not on the curve, 2 not torsion free): 0 valid (or a well-formed infinity), 1, 2 as decoded, 3 not on the curve, 4 not
+// in the subgroup (zkp_point_status).  A point that is not valid is flagged as infinity for the Miller loop (it contributes the
+// neutral line: no arithmetic on garbage) - its check is failed by k_checks_merge whatever the pairing product says.
+__global__ void k_points_merge(const uint8_t* dec, const uint8_t* val, uint8_t* inf, size_t n, uint8_t* st_out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t st = dec[i] ? dec[i] : (val[i] ? (uint8_t)(val[i] + 2) : (uint8_t)0);
+    st_out[i] = st;
+    if (st) inf[i] = 1;
+}
+__global__ void k_checks_merge(const uint8_t* st1, const uint8_t* st2, size_t n_checks, size_t k, uint8_t* ok, int* all_ok) {
+    size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_checks) return;
+    uint8_t bad = 0;
+    for (size_t j = 0; j < k; j++) bad |= st1[c * k + j] | st2[c * k + j];
+    if (bad) {
+        if (ok) ok[c] = 0;
+        if (all_ok) atomicAnd(all_ok, 0);
+    }
 }
 
 // every 6-limb element of a wire buffer must be < p
@@ -370,6 +417,12 @@ struct zkp_ctx {
     size_t host_slice = (size_t)1 << 19;
     hipDeviceProp_t prop;
     zkp::CoopState coop;
+    // zkp_points_check_batch: decoded points, infinity flags, decode / is_valid / merged status bytes, ok bytes (grow-only)
+    void* pc[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t pc_cap[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // one-rank-per-GPU communicator (zkp_comm_init_rank); null until then
+    ncclComm_t comm = nullptr;
+    int comm_nranks = 0, comm_rank = 0;
 };
 
 namespace {
@@ -674,7 +727,7 @@ struct HostCall {
 // =============================================================================== C ABI
 extern "C" {
 
-int zkp_abi_version(void) { return 2; }
+int zkp_abi_version(void) { return 3; }
 
 const char* zkp_strerror(int status) {
     switch (status) {
@@ -684,6 +737,7 @@ const char* zkp_strerror(int status) {
         case ZKP_ERR_HIP: return "HIP runtime error";
         case ZKP_ERR_NONCANONICAL: return "non-canonical field element in input";
         case ZKP_ERR_OOM: return "out of device memory";
+        case ZKP_ERR_COMM: return "RCCL error / no communicator";
         default: return "unknown status";
     }
 }
@@ -725,9 +779,12 @@ int zkp_init(int device, zkp_ctx** out_ctx) {
 void zkp_free(zkp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     zkp::coop_free(&c->coop);
     for (int i = 0; i < 8; i++)
         if (c->buf[i]) (void)hipFree(c->buf[i]);
+    for (int i = 0; i < 10; i++)
+        if (c->pc[i]) (void)hipFree(c->pc[i]);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->prod) (void)hipFree(c->prod);
     for (int i = 0; i < 2; i++) {
@@ -855,31 +912,124 @@ int zkp_pairing_gt_check_batch_dev(zkp_ctx* c, const void* g1, const void* g2, c
     return pairing_dev(c, (const uint64_t*)g1, (const uint64_t*)g2, (const uint8_t*)i1, (const uint8_t*)i2, n_checks, k, (uint64_t*)out_gt,
                        (uint8_t*)ok, (int*)all_ok, S(stream));
 }
+// is_valid of n G1 (which = 1) or G2 (which = 2) points on the context's kernel family, on stream s
+static int valid_dev(zkp_ctx* c, int which, const void* pts, const void* inf, size_t n, void* status, hipStream_t s) {
+    if (!n) return ZKP_OK;
+    if (zkp::coop_selected(&c->coop, c->kernel)) {
+        HIPCHK(c, which == 1 ? zkp::coop_g1_valid((const uint64_t*)pts, (const uint8_t*)inf, n, (uint8_t*)status, s)
+                             : zkp::coop_g2_valid((const uint64_t*)pts, (const uint8_t*)inf, n, (uint8_t*)status, s));
+        return ZKP_OK;
+    }
+    if (which == 1)
+        hipLaunchKernelGGL(k_g1_valid, dim3(grid_for(n, TPB)), dim3(TPB), 0, s, (const uint64_t*)pts, (const uint8_t*)inf, n, (uint8_t*)status);
+    else
+        hipLaunchKernelGGL(k_g2_valid, dim3(grid_for(n, TPB)), dim3(TPB), 0, s, (const uint64_t*)pts, (const uint8_t*)inf, n, (uint8_t*)status);
+    HIPCHK(c, hipGetLastError());
+    return ZKP_OK;
+}
 int zkp_g1_is_valid_batch_dev(zkp_ctx* c, const void* g1, const void* inf, size_t n, void* status, void* stream) {
     if (!c || too_many(n) || (n && (!g1 || !status))) return ZKP_ERR_ARG;
     DEV_ENTER(c, stream);
     if (!n) return ZKP_OK;
     if (int rc = validate_on_stream(c, g1, n * 2, S(stream))) return rc;
-    if (zkp::coop_selected(&c->coop, c->kernel)) {
-        HIPCHK(c, zkp::coop_g1_valid((const uint64_t*)g1, (const uint8_t*)inf, n, (uint8_t*)status, S(stream)));
-        return ZKP_OK;
-    }
-    hipLaunchKernelGGL(k_g1_valid, dim3(grid_for(n, TPB)), dim3(TPB), 0, S(stream), (const uint64_t*)g1, (const uint8_t*)inf, n, (uint8_t*)status);
-    HIPCHK(c, hipGetLastError());
-    return ZKP_OK;
+    return valid_dev(c, 1, g1, inf, n, status, S(stream));
 }
 int zkp_g2_is_valid_batch_dev(zkp_ctx* c, const void* g2, const void* inf, size_t n, void* status, void* stream) {
     if (!c || too_many(n) || (n && (!g2 || !status))) return ZKP_ERR_ARG;
     DEV_ENTER(c, stream);
     if (!n) return ZKP_OK;
     if (int rc = validate_on_stream(c, g2, n * 4, S(stream))) return rc;
-    if (zkp::coop_selected(&c->coop, c->kernel)) {
-        HIPCHK(c, zkp::coop_g2_valid((const uint64_t*)g2, (const uint8_t*)inf, n, (uint8_t*)status, S(stream)));
-        return ZKP_OK;
+    return valid_dev(c, 2, g2, inf, n, status, S(stream));
+}
+// ---- uncompressed point codec on resident buffers (round 4): the decode / encode kernels without the PCIe round trip
+static int codec_dev(zkp_ctx* c, bool decode, int nfp, const void* in, const void* inf_in, size_t n, void* out, void* out_inf, void* status,
+                     hipStream_t s) {
+    if (!n) return ZKP_OK;
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 7u) == 0;
+    if (decode) {
+        if (aligned)
+            hipLaunchKernelGGL(k_decode<true>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint8_t*)in, n, nfp, (uint64_t*)out, (uint8_t*)out_inf, (uint8_t*)status);
+        else
+            hipLaunchKernelGGL(k_decode<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint8_t*)in, n, nfp, (uint64_t*)out, (uint8_t*)out_inf, (uint8_t*)status);
+    } else {
+        if (aligned)
+            hipLaunchKernelGGL(k_encode<true>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint64_t*)in, (const uint8_t*)inf_in, n, nfp, (uint8_t*)out);
+        else
+            hipLaunchKernelGGL(k_encode<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint64_t*)in, (const uint8_t*)inf_in, n, nfp, (uint8_t*)out);
     }
-    hipLaunchKernelGGL(k_g2_valid, dim3(grid_for(n, TPB)), dim3(TPB), 0, S(stream), (const uint64_t*)g2, (const uint8_t*)inf, n, (uint8_t*)status);
     HIPCHK(c, hipGetLastError());
     return ZKP_OK;
+}
+int zkp_g1_decode_batch_dev(zkp_ctx* c, const void* bytes, size_t n, void* out_g1, void* out_inf, void* status, void* stream) {
+    if (!c || too_many(n) || (n && (!bytes || !out_g1 || !out_inf || !status))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    return codec_dev(c, true, 2, bytes, nullptr, n, out_g1, out_inf, status, S(stream));
+}
+int zkp_g2_decode_batch_dev(zkp_ctx* c, const void* bytes, size_t n, void* out_g2, void* out_inf, void* status, void* stream) {
+    if (!c || too_many(n) || (n && (!bytes || !out_g2 || !out_inf || !status))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    return codec_dev(c, true, 4, bytes, nullptr, n, out_g2, out_inf, status, S(stream));
+}
+int zkp_g1_encode_batch_dev(zkp_ctx* c, const void* g1, const void* inf, size_t n, void* out_bytes, void* stream) {
+    if (!c || too_many(n) || (n && (!g1 || !out_bytes))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    return codec_dev(c, false, 2, g1, inf, n, out_bytes, nullptr, nullptr, S(stream));
+}
+int zkp_g2_encode_batch_dev(zkp_ctx* c, const void* g2, const void* inf, size_t n, void* out_bytes, void* stream) {
+    if (!c || too_many(n) || (n && (!g2 || !out_bytes))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    return codec_dev(c, false, 4, g2, inf, n, out_bytes, nullptr, nullptr, S(stream));
+}
+
+// ---- BASELINE config 5 as ONE call: raw uncompressed bytes -> decode -> is_valid -> pairing check, everything between the byte
+// strings and the status / ok bytes resident in HBM (the context's workspace)
+static int ensure_pc(zkp_ctx* c, int slot, size_t bytes) {
+    if (bytes <= c->pc_cap[slot]) return ZKP_OK;
+    if (c->pc[slot]) { HIPCHK(c, hipFree(c->pc[slot])); c->pc[slot] = nullptr; c->pc_cap[slot] = 0; }
+    HIPCHK(c, hipMalloc(&c->pc[slot], bytes));
+    zkp_dbg_alloc("ctx.pc", c->pc[slot], bytes);
+    c->pc_cap[slot] = bytes;
+    return ZKP_OK;
+}
+enum { PC_G1 = 0, PC_G2, PC_INF1, PC_INF2, PC_DEC, PC_VAL, PC_ST1, PC_ST2, PC_OK, PC_BYTES };
+static int points_check_dev(zkp_ctx* c, const void* b1, const void* b2, size_t n_checks, size_t k, void* st1, void* st2, void* ok, int* all_ok,
+                            hipStream_t s) {
+    const size_t np = n_checks * k;
+    int rc;
+    if ((rc = ensure_pc(c, PC_G1, np * 96 + 8)) || (rc = ensure_pc(c, PC_G2, np * 192 + 8)) || (rc = ensure_pc(c, PC_INF1, np + 8)) ||
+        (rc = ensure_pc(c, PC_INF2, np + 8)) || (rc = ensure_pc(c, PC_DEC, 2 * np + 8)) || (rc = ensure_pc(c, PC_VAL, 2 * np + 8)) ||
+        (rc = ensure_pc(c, PC_ST1, np + 8)) || (rc = ensure_pc(c, PC_ST2, np + 8)) || (rc = ensure_pc(c, PC_OK, n_checks + 8)))
+        return rc;
+    uint8_t* dec1 = (uint8_t*)c->pc[PC_DEC];
+    uint8_t* dec2 = dec1 + np;
+    uint8_t* val1 = (uint8_t*)c->pc[PC_VAL];
+    uint8_t* val2 = val1 + np;
+    uint8_t* s1 = st1 ? (uint8_t*)st1 : (uint8_t*)c->pc[PC_ST1];
+    uint8_t* s2 = st2 ? (uint8_t*)st2 : (uint8_t*)c->pc[PC_ST2];
+    uint8_t* okb = ok ? (uint8_t*)ok : (uint8_t*)c->pc[PC_OK];
+    if (np) {
+        if ((rc = codec_dev(c, true, 2, b1, nullptr, np, c->pc[PC_G1], c->pc[PC_INF1], dec1, s)) ||
+            (rc = codec_dev(c, true, 4, b2, nullptr, np, c->pc[PC_G2], c->pc[PC_INF2], dec2, s)) ||
+            (rc = valid_dev(c, 1, c->pc[PC_G1], c->pc[PC_INF1], np, val1, s)) || (rc = valid_dev(c, 2, c->pc[PC_G2], c->pc[PC_INF2], np, val2, s)))
+            return rc;
+        hipLaunchKernelGGL(k_points_merge, dim3(grid_for(np, 256)), dim3(256), 0, s, dec1, val1, (uint8_t*)c->pc[PC_INF1], np, s1);
+        hipLaunchKernelGGL(k_points_merge, dim3(grid_for(np, 256)), dim3(256), 0, s, dec2, val2, (uint8_t*)c->pc[PC_INF2], np, s2);
+        HIPCHK(c, hipGetLastError());
+    }
+    if ((rc = pairing_dev(c, (const uint64_t*)c->pc[PC_G1], (const uint64_t*)c->pc[PC_G2], (const uint8_t*)c->pc[PC_INF1], (const uint8_t*)c->pc[PC_INF2],
+                          n_checks, k, nullptr, okb, all_ok, s)))
+        return rc;
+    if (n_checks && k) {
+        hipLaunchKernelGGL(k_checks_merge, dim3(grid_for(n_checks, 256)), dim3(256), 0, s, s1, s2, n_checks, k, okb, all_ok);
+        HIPCHK(c, hipGetLastError());
+    }
+    return ZKP_OK;
+}
+int zkp_points_check_batch_dev(zkp_ctx* c, const void* g1_bytes, const void* g2_bytes, size_t n_checks, size_t k, void* st1, void* st2, void* ok,
+                               void* all_ok, void* stream) {
+    if (!c || too_many(n_checks, k) || (n_checks && k && (!g1_bytes || !g2_bytes))) return ZKP_ERR_ARG;
+    DEV_ENTER(c, stream);
+    return points_check_dev(c, g1_bytes, g2_bytes, n_checks, k, st1, st2, ok, (int*)all_ok, S(stream));
 }
 int zkp_g1_mul_batch_dev(zkp_ctx* c, const void* base, size_t stride, const void* sc, size_t n, void* out, void* out_inf, void* stream) {
     if (!c || too_many(n) || (n && (!base || !sc || !out)) || (stride != 0 && stride != 12)) return ZKP_ERR_ARG;
@@ -1096,7 +1246,7 @@ static int codec_host(zkp_ctx* c, bool decode, int nfp, const void* in, const ui
     if ((rc = ensure(c, 0, nb)) || (rc = ensure(c, 4, nb)) || (rc = ensure(c, 2, n)) || (rc = ensure(c, 6, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->buf[0], in, nb, hipMemcpyHostToDevice, c->stream));
     if (decode) {
-        hipLaunchKernelGGL(k_decode, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const uint8_t*)c->buf[0], n, nfp, (uint64_t*)c->buf[4],
+        hipLaunchKernelGGL(k_decode<true>, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const uint8_t*)c->buf[0], n, nfp, (uint64_t*)c->buf[4],
                            (uint8_t*)c->buf[2], (uint8_t*)c->buf[6]);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(out, c->buf[4], nb, hipMemcpyDeviceToHost, c->stream));
@@ -1108,7 +1258,7 @@ static int codec_host(zkp_ctx* c, bool decode, int nfp, const void* in, const ui
             HIPCHK(c, hipMemcpyAsync(c->buf[2], inf_in, n, hipMemcpyHostToDevice, c->stream));
             di = (const uint8_t*)c->buf[2];
         }
-        hipLaunchKernelGGL(k_encode, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const uint64_t*)c->buf[0], di, n, nfp, (uint8_t*)c->buf[4]);
+        hipLaunchKernelGGL(k_encode<true>, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const uint64_t*)c->buf[0], di, n, nfp, (uint8_t*)c->buf[4]);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(out, c->buf[4], nb, hipMemcpyDeviceToHost, c->stream));
     }
@@ -1126,6 +1276,35 @@ int zkp_g1_encode_batch(zkp_ctx* c, const uint64_t* g1, const uint8_t* inf, size
 }
 int zkp_g2_encode_batch(zkp_ctx* c, const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* out) {
     return codec_host(c, false, 4, g2, inf, n, out, nullptr, nullptr);
+}
+
+int zkp_points_check_batch(zkp_ctx* c, const uint8_t* g1_bytes, const uint8_t* g2_bytes, size_t n_checks, size_t k, uint8_t* st1, uint8_t* st2,
+                           uint8_t* ok, int* all_ok) {
+    if (!c || too_many(n_checks, k) || (n_checks && k && (!g1_bytes || !g2_bytes))) return ZKP_ERR_ARG;
+    if (all_ok) *all_ok = 1;
+    if (!n_checks) return ZKP_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    HostCall drain(c);
+    const size_t np = n_checks * k;
+    if ((rc = ensure_pc(c, PC_BYTES, np * 288 + 8)) || (rc = ensure_pc(c, PC_ST1, np + 8)) || (rc = ensure_pc(c, PC_ST2, np + 8)) ||
+        (rc = ensure_pc(c, PC_OK, n_checks + 8)))
+        return rc;
+    uint8_t* d1 = (uint8_t*)c->pc[PC_BYTES];
+    uint8_t* d2 = d1 + np * 96;
+    if (np) {
+        HIPCHK(c, hipMemcpyAsync(d1, g1_bytes, np * 96, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d2, g2_bytes, np * 192, hipMemcpyHostToDevice, c->stream));
+    }
+    if ((rc = points_check_dev(c, d1, d2, n_checks, k, nullptr, nullptr, nullptr, c->d_flag + 1, c->stream))) return rc;
+    if (st1 && np) HIPCHK(c, hipMemcpyAsync(st1, c->pc[PC_ST1], np, hipMemcpyDeviceToHost, c->stream));
+    if (st2 && np) HIPCHK(c, hipMemcpyAsync(st2, c->pc[PC_ST2], np, hipMemcpyDeviceToHost, c->stream));
+    if (ok) HIPCHK(c, hipMemcpyAsync(ok, c->pc[PC_OK], n_checks, hipMemcpyDeviceToHost, c->stream));
+    int flag = 1;
+    HIPCHK(c, hipMemcpyAsync(&flag, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (all_ok) *all_ok = flag;
+    return ZKP_OK;
 }
 
 int zkp_fp_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
@@ -1155,8 +1334,9 @@ int zkp_fp_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, si
 }
 
 int zkp_tower_op_batch(zkp_ctx* c, int op, const uint64_t* a, const uint64_t* b, size_t n, uint32_t repeat, uint64_t* out) {
-    const bool binary = op == ZKP_TOWER_FP2_MUL || op == ZKP_TOWER_FP6_MUL || op == ZKP_TOWER_FP12_MUL || op == ZKP_TOWER_FP12_MUL_BY_014;
-    if (!c || op < 0 || op > ZKP_TOWER_FP12_CYCLOTOMIC_DECOMPRESS || n > 0x3fffffffu || (n && (!a || !out || (binary && !b)))) return ZKP_ERR_ARG;
+    const bool binary = op == ZKP_TOWER_FP2_MUL || op == ZKP_TOWER_FP6_MUL || op == ZKP_TOWER_FP12_MUL || op == ZKP_TOWER_FP12_MUL_BY_014 ||
+                        op == ZKP_TOWER_FP2_MUL_FP || op == ZKP_TOWER_FP6_MUL_BY_1 || op == ZKP_TOWER_FP6_MUL_BY_01;
+    if (!c || op < 0 || op > ZKP_TOWER_FP12_INVERT || n > 0x3fffffffu || (n && (!a || !out || (binary && !b)))) return ZKP_ERR_ARG;
     if (op == ZKP_TOWER_FP12_CYCLOTOMIC_DECOMPRESS && !zkp::coop_selected(&c->coop, c->kernel)) return ZKP_ERR_ARG;
     if (op == ZKP_TOWER_FP12_CYCLOTOMIC_POW2K && (repeat < 1 || repeat > 64)) return ZKP_ERR_ARG;
     if (!n) return ZKP_OK;
@@ -1257,6 +1437,122 @@ int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1,
     return multi_impl(ctxs, n_ctx, g1, g2, inf1, inf2, n, 1, out_gt, ok, all_ok);
 }
 
+// ---------------------------------------------------------------- one rank per GPU: the RCCL collective behind the ABI
+#define NCCLCHK(ctx, call)                                                                      \
+    do {                                                                                        \
+        ncclResult_t r__ = (call);                                                              \
+        if (r__ != ncclSuccess) {                                                               \
+            (ctx)->err = std::string(#call) + ": " + ncclGetErrorString(r__);                   \
+            return ZKP_ERR_COMM;                                                                \
+        }                                                                                       \
+    } while (0)
+static_assert(ZKP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the header's id size is RCCL's");
+
+int zkp_comm_unique_id(void* out_id) {
+    if (!out_id) return ZKP_ERR_ARG;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return ZKP_ERR_COMM;
+    memcpy(out_id, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return ZKP_OK;
+}
+int zkp_comm_init_rank(zkp_ctx* c, int nranks, int rank, const void* unique_id) {
+    if (!c || !unique_id || nranks < 1 || rank < 0 || rank >= nranks) return ZKP_ERR_ARG;
+    if (c->comm) { c->err = "the context already has a communicator"; return ZKP_ERR_ARG; }
+    int rc = bind(c);
+    if (rc) return rc;
+    ncclUniqueId id;
+    memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
+    NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    c->comm_nranks = nranks;
+    c->comm_rank = rank;
+    return ZKP_OK;
+}
+int zkp_comm_destroy(zkp_ctx* c) {
+    if (!c) return ZKP_ERR_ARG;
+    if (!c->comm) return ZKP_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ncclComm_t comm = c->comm;
+    c->comm = nullptr;
+    c->comm_nranks = c->comm_rank = 0;
+    NCCLCHK(c, ncclCommDestroy(comm));
+    return ZKP_OK;
+}
+int zkp_comm_info(const zkp_ctx* c, int* nranks, int* rank) {
+    if (!c) return ZKP_ERR_ARG;
+    if (nranks) *nranks = c->comm ? c->comm_nranks : 0;
+    if (rank) *rank = c->comm ? c->comm_rank : 0;
+    return ZKP_OK;
+}
+// AND of {0,1} flags = MIN (RCCL has no bitwise AND): ONE ncclAllReduce(count = 1, ncclInt32, ncclMin), in place
+static int and_allreduce(zkp_ctx* c, int* d_flag, hipStream_t s) {
+    if (!c->comm) { c->err = "no communicator: call zkp_comm_init_rank first"; return ZKP_ERR_COMM; }
+    NCCLCHK(c, ncclAllReduce(d_flag, d_flag, 1, ncclInt32, ncclMin, c->comm, s));
+    return ZKP_OK;
+}
+int zkp_and_allreduce_dev(zkp_ctx* c, void* d_flag, void* stream) {
+    if (!c || !d_flag) return ZKP_ERR_ARG;
+    int rc = bind(c);
+    if (rc) return rc;
+    return and_allreduce(c, (int*)d_flag, S(stream));
+}
+int zkp_pairing_check_batch_allreduce_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n_checks, size_t k,
+                                          void* ok, void* all_ok, void* stream) {
+    if (!c || !all_ok) return ZKP_ERR_ARG;
+    if (!c->comm) { c->err = "no communicator: call zkp_comm_init_rank first"; return ZKP_ERR_COMM; }
+    int rc = zkp_pairing_check_batch_dev(c, g1, g2, i1, i2, n_checks, k, ok, all_ok, stream);   // a rank with an empty block still sets its flag to 1
+    if (rc) return rc;
+    return and_allreduce(c, (int*)all_ok, S(stream));
+}
+int zkp_pairing_check_batch_allreduce(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks,
+                                      size_t k, uint8_t* ok, int* all_ok) {
+    if (!c || !all_ok) return ZKP_ERR_ARG;
+    if (!c->comm) { c->err = "no communicator: call zkp_comm_init_rank first"; return ZKP_ERR_COMM; }
+    // the rank's own block through the host-pointer entry point (uploads, kernels, downloads; it leaves the local AND in *all_ok),
+    // then the flag goes back to the device for the collective: every rank calls this exactly once per global check, whatever
+    // its own block's size or status - a rank that failed locally still takes part (with flag 0) so that no peer hangs
+    int local = 1;
+    const int rc_local = zkp_pairing_check_batch(c, g1, g2, inf1, inf2, n_checks, k, ok, &local);
+    if (rc_local) local = 0;
+    int rc = bind(c);
+    if (rc) return rc;
+    HostCall drain(c);
+    HIPCHK(c, hipMemcpyAsync(c->d_flag + 1, &local, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if ((rc = and_allreduce(c, c->d_flag + 1, c->stream))) return rc;
+    int all = 0;
+    HIPCHK(c, hipMemcpyAsync(&all, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *all_ok = all;
+    return rc_local;
+}
+int zkp_pairing_product_check_allgather(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n,
+                                        uint64_t* out_gt, int* is_one) {
+    if (!c || (n && (!g1 || !g2)) || n > 0x7fffffffu) return ZKP_ERR_ARG;
+    if (!c->comm) { c->err = "no communicator: call zkp_comm_init_rank first"; return ZKP_ERR_COMM; }
+    int rc = bind(c);
+    if (rc) return rc;
+    HostCall drain(c);
+    const size_t R = (size_t)c->comm_nranks;
+    // this rank's Miller product -> c->prod[0..72) (the identity for an empty block), gathered into slot 5 (R records)
+    Staged st = {nullptr, nullptr, nullptr, nullptr};
+    if (n && (rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st))) return rc;
+    if ((rc = ensure_prod(c, (n / 8 + 1 > R ? n / 8 + 1 : R))) || (rc = ensure(c, 5, R * 576)) || (rc = ensure(c, 4, 576))) return rc;
+    if ((rc = miller_product_dev(c, st.g1, st.g2, st.i1, st.i2, n, n ? nullptr : c->prod, c->stream))) return rc;
+    NCCLCHK(c, ncclAllGather(c->prod, c->buf[5], 72, ncclUint64, c->comm, c->stream));
+    uint64_t* const total = c->prod + 72 * R;      // a spare record (ensure_prod keeps two behind the R the tree works on)
+    if ((rc = fp12_product_dev(c, (const uint64_t*)c->buf[5], R, total, c->stream))) return rc;
+    if ((rc = final_exp_dev(c, total, 1, (uint64_t*)c->buf[4], c->stream))) return rc;
+    hipLaunchKernelGGL(k_gt_is_one, dim3(1), dim3(64), 0, c->stream, (const uint64_t*)c->buf[4], c->d_flag);
+    HIPCHK(c, hipGetLastError());
+    int one = 0;
+    if (out_gt) HIPCHK(c, hipMemcpyAsync(out_gt, c->buf[4], 576, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&one, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (is_one) *is_one = one;
+    return ZKP_OK;
+}
+
 // page-locked host memory for the host-pointer entry points (header: "pinned host memory")
 int zkp_host_alloc(size_t bytes, void** out_ptr) {
     if (!out_ptr || !bytes) return ZKP_ERR_ARG;
@@ -1272,13 +1568,15 @@ int zkp_host_free(void* ptr) {
 int zkp_host_register(void* ptr, size_t bytes) {
     if (!ptr || !bytes) return ZKP_ERR_ARG;
     // whole pages of its own only (header: pinned host memory): registrations that share a page corrupt the runtime's bookkeeping
-    if (((uintptr_t)ptr | bytes) & 4095u) return ZKP_ERR_ARG;
+    static const long page = sysconf(_SC_PAGESIZE) > 0 ? sysconf(_SC_PAGESIZE) : 4096;
+    if (((uintptr_t)ptr | bytes) & (uintptr_t)(page - 1)) return ZKP_ERR_ARG;
     zkp_dbg_alloc("host_register", ptr, bytes);
     return hipHostRegister(ptr, bytes, hipHostRegisterPortable) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP;
 }
 int zkp_host_unregister(void* ptr) {
+    if (!ptr) return ZKP_ERR_ARG;
     zkp_dbg_alloc("host_unregister", ptr, 0);
-    return ptr && hipHostUnregister(ptr) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP;
+    return hipHostUnregister(ptr) == hipSuccess ? ZKP_OK : ZKP_ERR_HIP;
 }
 
 // measurement helper: a one-wavefront clock probe on `stream` (asynchronous); d_out receives two u64: shader clock ticks

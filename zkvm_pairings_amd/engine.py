@@ -114,7 +114,9 @@ class PairingEngine:
     def pairing(self, g1, g2, inf1=None, inf2=None, out=None):
         """out[i] = pairing(g1[i], g2[i])  -> (n,72) canonical Gt (into `out` when given, e.g. a host_array)"""
         if _is_torch(g1):
-            return self._pairing_t(g1, g2, inf1, inf2)
+            if out is not None and not _is_torch(out):
+                raise ValueError("out must be a tensor on the engine's GPU when the inputs are")
+            return self._pairing_t(g1, g2, inf1, inf2, out)
         g1, g2 = _np(g1, 12), _np(g2, 24)
         n = g1.shape[0]
         if g2.shape[0] != n:
@@ -283,9 +285,127 @@ class PairingEngine:
         self._chk(fn(self._h, _ptr(pts), _ptr(i), n, _ptr(out)))
         return out.tobytes()
 
+    # ---- BASELINE config 5 in one call, and the codec on resident tensors
+    POINT_STATUS = ("ok", "non_canonical", "malformed", "not_on_curve", "not_in_subgroup")
+
+    def points_check(self, g1_bytes, g2_bytes, k, st1=None, st2=None, ok=None, all_ok=None):
+        """raw uncompressed points -> decode -> is_valid -> pairing check (zkp_points_check_batch[_dev]).
+        numpy uint8 arrays (n x 96, n x 192): returns (st1, st2, ok, all_ok bool).  torch uint8 tensors on the engine's GPU:
+        fills the given st1 / st2 / ok (uint8) and all_ok (int32[1]) tensors - each optional - asynchronously, returns None."""
+        if _is_torch(g1_bytes):
+            import torch
+            u8 = (torch.uint8,)
+            self._t_check(g1_bytes, 96, "g1_bytes", dtypes=u8), self._t_check(g2_bytes, 192, "g2_bytes", dtypes=u8)
+            n = g1_bytes.numel() // 96
+            if g2_bytes.numel() // 192 != n or k <= 0 or n % k:
+                raise ValueError("byte strings / k do not match")
+            self._t_bytes(st1, n, "st1"), self._t_bytes(st2, n, "st2"), self._t_bytes(ok, n // k, "ok")
+            if all_ok is not None:
+                self._t_check(all_ok, None, "all_ok", rows=1, dtypes=(torch.int32,))
+            self._chk(self._lib.zkp_points_check_batch_dev(self._h, self._tp(g1_bytes), self._tp(g2_bytes), n // k, k, self._tp(st1), self._tp(st2),
+                                                           self._tp(ok), self._tp(all_ok), self._stream()))
+            return None
+        b1 = np.ascontiguousarray(g1_bytes, dtype=np.uint8).reshape(-1, 96)
+        b2 = np.ascontiguousarray(g2_bytes, dtype=np.uint8).reshape(-1, 192)
+        n = b1.shape[0]
+        if b2.shape[0] != n or k <= 0 or n % k:
+            raise ValueError("byte strings / k do not match")
+        s1, s2, okb = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8), np.empty(n // k, dtype=np.uint8)
+        allok = ctypes.c_int(1)
+        self._chk(self._lib.zkp_points_check_batch(self._h, _ptr(b1), _ptr(b2), n // k, k, _ptr(s1), _ptr(s2), _ptr(okb), ctypes.byref(allok)))
+        return s1, s2, okb, bool(allok.value)
+
+    def decode_points_dev(self, data, which):
+        """uint8 tensor of uncompressed points on the engine's GPU -> (points int64 (n, 12 | 24), inf uint8, status uint8) tensors"""
+        import torch
+        size = 96 if which == 1 else 192
+        self._t_check(data, size, "bytes", dtypes=(torch.uint8,))
+        n = data.numel() // size
+        pts = torch.empty((n, size // 8), dtype=torch.int64, device=data.device)
+        inf = torch.empty(n, dtype=torch.uint8, device=data.device)
+        st = torch.empty(n, dtype=torch.uint8, device=data.device)
+        fn = self._lib.zkp_g1_decode_batch_dev if which == 1 else self._lib.zkp_g2_decode_batch_dev
+        self._chk(fn(self._h, self._tp(data), n, self._tp(pts), self._tp(inf), self._tp(st), self._stream()))
+        return pts, inf, st
+
+    def encode_points_dev(self, pts, which, inf=None):
+        """(n, 12 | 24) point tensor on the engine's GPU -> (n, 96 | 192) uint8 tensor of uncompressed big-endian points"""
+        import torch
+        cols = 12 if which == 1 else 24
+        self._t_check(pts, cols, "points")
+        n = pts.numel() // cols
+        self._t_bytes(inf, n, "inf")
+        out = torch.empty((n, cols * 8), dtype=torch.uint8, device=pts.device)
+        fn = self._lib.zkp_g1_encode_batch_dev if which == 1 else self._lib.zkp_g2_encode_batch_dev
+        self._chk(fn(self._h, self._tp(pts), self._tp(inf), n, self._tp(out), self._stream()))
+        return out
+
+    # ---- one rank per GPU: the RCCL communicator behind the C ABI (the torch.distributed flavour is zkvm_pairings_amd/dist.py)
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes made on rank 0; every rank hands the same bytes to comm_init_rank"""
+        buf = ctypes.create_string_buffer(128)
+        st = _lib.load().zkp_comm_unique_id(buf)
+        if st != 0:
+            raise _lib.ZkpError(st, "zkp_comm_unique_id")
+        return buf.raw
+
+    def comm_init_rank(self, nranks, rank, unique_id):
+        if len(unique_id) != 128:
+            raise ValueError("the communicator id is 128 bytes")
+        self._chk(self._lib.zkp_comm_init_rank(self._h, int(nranks), int(rank), ctypes.c_char_p(bytes(unique_id))))
+
+    def comm_destroy(self):
+        self._chk(self._lib.zkp_comm_destroy(self._h))
+
+    def comm_info(self):
+        n, r = ctypes.c_int(), ctypes.c_int()
+        self._chk(self._lib.zkp_comm_info(self._h, ctypes.byref(n), ctypes.byref(r)))
+        return n.value, r.value
+
+    def and_allreduce(self, flag):
+        """in-place AND (all-reduce MIN) of an int32[1] tensor of {0,1} over the communicator's ranks, on the current stream"""
+        import torch
+        self._t_check(flag, None, "flag", rows=1, dtypes=(torch.int32,))
+        self._chk(self._lib.zkp_and_allreduce_dev(self._h, self._tp(flag), self._stream()))
+
+    def pairing_check_allreduce(self, g1, g2, k, inf1=None, inf2=None):
+        """this rank's block of a sharded check + the AND over all ranks (zkp_pairing_check_batch_allreduce[_dev]):
+        -> (ok bytes of this rank's checks, all_ok over ALL ranks: bool for host arrays, int32[1] tensor for device tensors)"""
+        if _is_torch(g1):
+            import torch
+            n = self._t_pairs(g1, g2, inf1, inf2, k)
+            ok = torch.empty(n // k, dtype=torch.uint8, device=g1.device)
+            allok = torch.empty(1, dtype=torch.int32, device=g1.device)
+            self._chk(self._lib.zkp_pairing_check_batch_allreduce_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), n // k, k,
+                                                                      self._tp(ok), self._tp(allok), self._stream()))
+            return ok, allok
+        g1, g2 = _np(g1, 12), _np(g2, 24)
+        n = g1.shape[0]
+        if g2.shape[0] != n or k <= 0 or n % k:
+            raise ValueError("g1 / g2 sizes do not match or are not a multiple of k")
+        i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
+        ok = np.empty(n // k, dtype=np.uint8)
+        allok = ctypes.c_int(1)
+        self._chk(self._lib.zkp_pairing_check_batch_allreduce(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n // k, k, _ptr(ok), ctypes.byref(allok)))
+        return ok, bool(allok.value)
+
+    def pairing_product_check_allgather(self, g1, g2, inf1=None, inf2=None):
+        g1, g2 = _np(g1, 12), _np(g2, 24)
+        n = g1.shape[0]
+        if g2.shape[0] != n:
+            raise ValueError("g1 and g2 hold different numbers of points")
+        i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
+        gt = np.empty(72, dtype=np.uint64)
+        one = ctypes.c_int(0)
+        self._chk(self._lib.zkp_pairing_product_check_allgather(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n, _ptr(gt), ctypes.byref(one)))
+        return gt, bool(one.value)
+
     FP_OPS = {"mul": 0, "add": 1, "sub": 2, "neg": 3, "square": 4, "invert": 5}
     TOWER_OPS = {"fp2_mul": 0, "fp2_square": 1, "fp6_mul": 2, "fp6_square": 3, "fp6_frobenius": 4, "fp12_mul": 5, "fp12_square": 6,
-                 "fp12_mul_by_014": 7, "fp12_frobenius": 8, "fp12_conjugate": 9, "fp12_cyclotomic_square": 10, "fp12_cyclotomic_pow2k": 11, "fp12_cyclotomic_decompress": 12}
+                 "fp12_mul_by_014": 7, "fp12_frobenius": 8, "fp12_conjugate": 9, "fp12_cyclotomic_square": 10, "fp12_cyclotomic_pow2k": 11, "fp12_cyclotomic_decompress": 12,
+                 "fp2_invert": 13, "fp2_mul_by_nonresidue": 14, "fp2_mul_fp": 15, "fp6_mul_by_1": 16, "fp6_mul_by_01": 17, "fp6_mul_by_nonresidue": 18,
+                 "fp6_invert": 19, "fp12_invert": 20}
 
     def fp_op(self, op, a, b=None, core28=False):
         """zkVM-precompile-shaped batched field op: op 0 = mul, 1 = add (reference src/fp.rs:376,443), 2 sub, 3 neg,
