@@ -192,6 +192,12 @@ class Emu:
         val = ((1 << 64) - 1 if self.exec == (1 << self.n) - 1 else self.exec) if a[1] == "exec" else self.rd(a[1], 0)
         self.s[lo], self.s[lo + 1] = val & M32, (val >> 32) & M32
 
+    def op_s_and_b64(self, a, m):
+        lo = int(re.match(r"s\[(\d+):", a[0]).group(1))
+        val = self.rd(a[1], 0) & self.rd(a[2], 0)
+        self.s[lo], self.s[lo + 1] = val & M32, (val >> 32) & M32
+        self.scc = int(val != 0)
+
     def _sr(self, x):
         x = x.strip()
         return self.s[int(x[1:])] if re.fullmatch(r"s\d+", x) else int(x, 0) & M32
@@ -289,6 +295,16 @@ class Emu:
                     if addr + 4 * k not in self.lds:
                         raise RuntimeError("LDS read of unwritten address %d" % (addr + 4 * k))
                 self.wr(a[0], lane, sum(self.lds[addr + 4 * k] << (32 * k) for k in range(4)), 4)
+
+    def op_ds_write_b64(self, a, m):
+        off = m.get("offset", 0)
+        for lane in range(self.n):
+            if (self.exec >> lane) & 1:
+                addr = self.rd(a[0], lane) + off
+                assert addr % 8 == 0
+                val = self.rd(a[1], lane, 2)
+                for k in range(2):
+                    self.lds[addr + 4 * k] = (val >> (32 * k)) & M32
 
     def op_ds_write_b128(self, a, m):
         off = m.get("offset", 0)

@@ -193,21 +193,23 @@ def term(g, p, first, tag):
             acc(("a", NL + i + j), g.ACC[NL + i + j], A + NH + i, B + NH + j)
 
 
-def tail(g, out):
-    """fold, Montgomery reduction, limb extraction -> 14 registers from out"""
+def tail(g, out, fold=True):
+    """fold, Montgomery reduction, limb extraction -> 14 registers from out.
+    fold=False: the accumulation holds plain (schoolbook) columns only - ksqr_plain: columns 0..26 as they stand, column 13 in MID[6]"""
     D = g.D
     col = dict(g.ACC)
-    # fold: mid[k] += lo[k] + hi[k]; column 7 + k += mid[k]  (column 13 has no product of its own: it IS mid[6])
-    for k in range(13):
-        g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (g.MID[k], g.MID[k] + 1, g.MID[k], g.MID[k] + 1, g.ACC[k], g.ACC[k] + 1))
-    for k in range(13):
-        g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (g.MID[k], g.MID[k] + 1, g.MID[k], g.MID[k] + 1, g.ACC[NL + k], g.ACC[NL + k] + 1))
     col[13] = g.MID[6]
-    for k in range(13):
-        if k == 6:
-            continue
-        c = col[NH + k]
-        g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (c, c + 1, c, c + 1, g.MID[k], g.MID[k] + 1))
+    if fold:
+        # fold: mid[k] += lo[k] + hi[k]; column 7 + k += mid[k]  (column 13 has no product of its own: it IS mid[6])
+        for k in range(13):
+            g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (g.MID[k], g.MID[k] + 1, g.MID[k], g.MID[k] + 1, g.ACC[k], g.ACC[k] + 1))
+        for k in range(13):
+            g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (g.MID[k], g.MID[k] + 1, g.MID[k], g.MID[k] + 1, g.ACC[NL + k], g.ACC[NL + k] + 1))
+        for k in range(13):
+            if k == 6:
+                continue
+            c = col[NH + k]
+            g.e("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (c, c + 1, c, c + 1, g.MID[k], g.MID[k] + 1))
     # reduction, row i: m = (low word of column i * PINV) mod 2^28; column i + j += m p_j; column i + 1 += column i >> 28.
     # Emission order per row: m, the j = 0 and j = 1 products, the carry - then the twelve remaining products of the
     # PREVIOUS row fill the latency of the next row's m.
@@ -355,6 +357,57 @@ def kterm(g, A, B, first):
             acc(("m", i + j), g.MID[i + j], D + i, D + NH + j)
 
 
+def ksqr_plain(g, A, P1=None, P2=None):
+    """acc = sum_i P1[i] A[i] w^2i + sum_{i<j} P2[i] A[j] w^(i+j): a square in 105 multiply-adds instead of the 147 of a Karatsuba
+    product.  Default P1 = A and P2 = 2A (formed in D): acc = A^2; a scaled square s A^2 takes P1 = s A, P2 = 2 s A.  Plain columns
+    (column 13 in MID[6]): the accumulation holds nothing else and is reduced by tail(fold=False) - no fold of Karatsuba halves."""
+    if P2 is None:
+        assert P1 is None
+        P1, P2 = A, g.D
+        for i in range(NL):
+            g.e("v_lshlrev_b32 v%d, 1, v%d" % (P2 + i, A + i))
+    col = dict(g.ACC)
+    col[13] = g.MID[6]
+    touched = set()
+    for i in range(NL):
+        for j in range(i, NL):
+            k = i + j
+            add = col[k] if k in touched else None
+            touched.add(k)
+            g.mad(col[k], vreg((P1 if i == j else P2) + i), vreg(A + j), add)
+
+
+def ksqr_k(g, A, P1, P2, first):
+    """the same value, sum_i P1[i] A[i] w^2i + sum_{i<j} P2[i] A[j] w^(i+j) with P1 = s A and P2 = 2 s A, accumulated in the
+    Karatsuba layout of kterm (low halves -> columns 0..12, high halves -> 14..26, the subtractive middle term
+    (a_hi - a_lo)(b_lo - b_hi) = -s (a_hi - a_lo)^2 -> MID) so that it can share a lazy accumulation - and its fold - with kterm
+    products: 84 multiply-adds + 21 subtractions.  P2 is destroyed (its low half receives the middle term's doubled differences)."""
+    D = g.D
+    touched = set()
+
+    def acc(key, dst, a, b):
+        add = dst
+        if first and key not in touched:
+            add = None
+            touched.add(key)
+        g.mad(dst, vreg(a), vreg(b), add)
+
+    for h, cols in ((0, 0), (NH, NL)):
+        for i in range(NH):
+            for j in range(i, NH):
+                acc(("a", cols + i + j), g.ACC[cols + i + j], (P1 if i == j else P2) + h + i, A + h + j)
+    # middle term: dq = a_hi - a_lo (D[0..6]), dp1 = P1_lo - P1_hi = -s dq (D[7..13]), dp2 = P2_lo - P2_hi (in place, P2's low half)
+    for i in range(NH):
+        g.e("v_sub_u32 v%d, v%d, v%d" % (D + i, A + NH + i, A + i))
+    for i in range(NH):
+        g.e("v_sub_u32 v%d, v%d, v%d" % (D + NH + i, P1 + i, P1 + NH + i))
+    for i in range(NH):
+        g.e("v_sub_u32 v%d, v%d, v%d" % (P2 + i, P2 + i, P2 + NH + i))
+    for i in range(NH):
+        for j in range(i, NH):
+            acc(("m", i + j), g.MID[i + j], (D + NH + i) if i == j else (P2 + i), D + j)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # k_ksq: one compressed squaring per loop iteration.  The block continues the Fp2 product above with everything that
 # follows it in the iteration except the rare snapshot store and the operand forms of the next product (C++):
@@ -416,6 +469,8 @@ def generate_ksq(vb=6):
     for (sr, m) in ((g.sMA, 0x55555555), (g.sM1, 0x22222222)):
         g.e("s_mov_b32 s%d, 0x%x" % (sr, m))
         g.e("s_mov_b32 s%d, 0x%x" % (sr + 1, m))
+        # inside the entry EXEC (k_ksq runs full wavefronts; nothing here depends on that)
+        g.e("s_and_b64 s[%d:%d], s[%d:%d], s[%d:%d]" % (sr, sr + 1, sr, sr + 1, g.sEX, g.sEX + 1))
     for i, v in enumerate(p_balanced()):
         g.e("s_mov_b32 s%d, 0x%x" % (g.sPB + i, v & 0xffffffff))
     g.e("v_mov_b32 v%d, 6" % mul)

@@ -189,6 +189,8 @@ class Prep:
         for (sr, m) in ((self.sM0, 0x55555555), (self.sM1, 0xaaaaaaaa)):
             self.e("s_mov_b32 s%d, 0x%x" % (sr, m))
             self.e("s_mov_b32 s%d, 0x%x" % (sr + 1, m))
+            # the lane-role masks stay INSIDE the entry EXEC: a caller with lanes switched off never has them switched on here
+            self.e("s_and_b64 s[%d:%d], s[%d:%d], s[%d:%d]" % (sr, sr + 1, sr, sr + 1, self.sEX, self.sEX + 1))
         self.e("s_mov_b64 vcc, s[%d:%d]" % (self.sM1, self.sM1 + 1))
         for i, v in enumerate(p_balanced()):
             self.e("s_mov_b32 s%d, 0x%x" % (self.sPB + i, v & 0xffffffff))

@@ -50,6 +50,13 @@
 #if ZKP_PREP_ASM
 #include "zkp_prep_dbl.inc"
 #endif
+#ifndef ZKP_VALID_ASM
+#define ZKP_VALID_ASM ZKP_COOP_ASM   // the Jacobian doubling / mixed addition of the subgroup checks as asm blocks (tools/validasm.py ->
+                                     // zkp_valid_steps.inc): k_g1_valid_fast / k_g2_valid_fast; 0: the compiled kernels only (round 3)
+#endif
+#if ZKP_VALID_ASM
+#include "zkp_valid_steps.inc"
+#endif
 
 using namespace zkp28;
 
@@ -1394,9 +1401,13 @@ __device__ __forceinline__ bool jac_eq_affine(const F& f, const JacP& p, const F
 }
 
 // one lane per point: 0 valid / 1 not on curve / 2 not torsion free  (-[X^2]P == (beta x, y), src/g1.rs:111-115)
-__global__ void __launch_bounds__(64, 2) k_g1_valid28(const uint64_t* g1, const uint8_t* inf, uint32_t n, uint8_t* status) {
+// redo_only: the asm kernel ran first and left VALID_REDO where its chain met an exceptional case of the group law (infinity,
+// P + P, P - P, order two: points outside the prime-order subgroup only) - this kernel, which handles every case, redoes those
+constexpr uint8_t VALID_REDO = 0xff;
+__global__ void __launch_bounds__(64, 2) k_g1_valid28(const uint64_t* g1, const uint8_t* inf, uint32_t n, uint8_t* status, int redo_only) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
+    if (redo_only && status[i] != VALID_REDO) return;
     if (inf && inf[i]) { status[i] = 0; return; }
     F1 f{0};
     Fp28 x, y;
@@ -1418,12 +1429,14 @@ __global__ void __launch_bounds__(64, 2) k_g1_valid28(const uint64_t* g1, const 
 }
 
 // two lanes per point: psi(P) == -[X]P  (src/g2.rs:166-170)
-__global__ void __launch_bounds__(64, 2) k_g2_valid28(const uint64_t* g2, const uint8_t* inf, uint32_t n, uint8_t* status) {
+__global__ void __launch_bounds__(64, 2) k_g2_valid28(const uint64_t* g2, const uint8_t* inf, uint32_t n, uint8_t* status, int redo_only) {
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
     const int c = (int)(tid & 1);
     uint32_t i = tid >> 1;
     const bool live = i < n;
     if (!live) i = n - 1;
+    if (redo_only && !__any(live && status[i] == VALID_REDO)) return;      // wave-uniform: both lanes of a pair stay together
+    const bool keep = redo_only && status[i] != VALID_REDO;
     const bool is_inf = inf && inf[i];
     __shared__ int4 park[2 * 4 * 64];
     const int lane = threadIdx.x;
@@ -1450,8 +1463,148 @@ __global__ void __launch_bounds__(64, 2) k_g2_valid28(const uint64_t* g2, const 
         Fp28 px = f.mul(cx, kx), py = f.mul(cy, ky);
         st = jac_eq_affine(f, p, px, c_neg(py)) ? 0 : 2;
     }
-    if (live && c == 0) status[i] = is_inf ? 0 : st;
+    if (live && c == 0 && !keep) status[i] = is_inf ? 0 : st;
 }
+
+#if ZKP_VALID_ASM
+// ---- the same two checks with the chain's steps as asm blocks (tools/validasm.py).  No exceptional case of the group law is
+// handled in the steps: each of them sends Z to 0, Z = 0 is absorbing, and a chain that ends with Z = 0 mod p is handed to
+// the generic kernel above (status VALID_REDO; launched behind this one with redo_only).  A point of the prime-order subgroup
+// never takes that route: the chains' scalars (x^2, |x|) are below r.
+// one lane per point, three waves per SIMD: -[x^2] P == (beta x, y)  (src/g1.rs:111-115)
+__global__ void __launch_bounds__(64, 3) k_g1_valid_fast(const uint64_t* g1, const uint8_t* inf, uint32_t n, uint8_t* status) {
+    extern __shared__ int4 park[];          // slots 0, 1: the affine point, 2: the addition's parked value; at LDS address 0
+    const int lane = threadIdx.x;
+    uint32_t i = blockIdx.x * 64 + lane;
+    const bool live = i < n;
+    if (!live) i = n - 1;
+    const bool is_inf = inf && inf[i];
+    bool on;
+    int32_t X[NL], Y[NL], Z[NL];
+    {
+        Fp28 x, y;
+        fp28_from_wire(x, g1 + 12 * (size_t)i);
+        fp28_from_wire(y, g1 + 12 * (size_t)i + 6);
+        Fp28 lhs, t, rhs;
+        fp28_mul(lhs, y, y);
+        fp28_mul(t, x, x);
+        fp28_mul(rhs, t, x);
+        on = f_is_zero(c_sub(lhs, c_add(rhs, f_const(K28_B))));
+        valid_park(park, lane, 0, x);
+        valid_park(park, lane, 1, y);
+#pragma unroll
+        for (int k = 0; k < NL; k++) { X[k] = x.l[k]; Y[k] = y.l[k]; Z[k] = K28_ONE[k]; }
+    }
+    if (!__any(on && !is_inf)) {            // wave-uniform: nothing to multiply
+        if (live) status[i] = is_inf ? 0 : 1;
+        return;
+    }
+    // the blocks own v6..v167 of the 168 registers of three waves per SIMD: what the epilogue needs of the lane is ONE packed
+    // register here and is re-derived from an opaque copy of the lane number behind the loop
+    int flags = (on ? 1 : 0) | (is_inf ? 2 : 0);
+    static_assert(NL == 14, "the generated blocks are for 14 limbs");
+#define ZKP_G1_STEP(BLOCK)                                                                                                               \
+    do {                                                                                                                                 \
+        constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};                                                                                     \
+        asm volatile(BLOCK                                                                                                               \
+                     : ZKP_G1_STEP_IO(X, Y, Z)                                                                                           \
+                     : [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]),            \
+                       [p6] "s"(PL[6]), [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]),        \
+                       [p12] "s"(PL[12]), [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)                                                      \
+                     : ZKP_G1_STEP_CLOBBERS);                                                                                            \
+    } while (0)
+    // X^2 = 0xac45a4010001a402_0000000100000000 (X = 0xd201000000010000): the accumulator starts at P (the leading one), then
+    // one doubling per remaining bit and an addition where the bit is set
+    const uint64_t hi = 0xac45a4010001a402ULL, lo = 0x0000000100000000ULL;
+#pragma unroll 1
+    for (int b = 126; b >= 0; b--) {
+        ZKP_G1_STEP(ZKP_G1_DBL_ASM);
+        if (((b >= 64 ? hi >> (b - 64) : lo >> b) & 1) != 0) ZKP_G1_STEP(ZKP_G1_MADD_ASM);
+    }
+    int l_ = threadIdx.x;
+    asm volatile("" : "+v"(l_), "+v"(flags));
+    Fp28 px, py, pz;
+#pragma unroll
+    for (int k = 0; k < NL; k++) { px.l[k] = X[k]; py.l[k] = Y[k]; pz.l[k] = Z[k]; }
+    uint8_t st;
+    if (f_is_zero(pz)) {
+        st = VALID_REDO;
+    } else {
+        Fp28 z2, z3, bx, t;
+        fp28_mul(z2, pz, pz);
+        fp28_mul(z3, z2, pz);
+        fp28_mul(bx, valid_unpark(park, l_, 0), f_const(K28_BETA));
+        fp28_mul(t, bx, z2);
+        const bool ex = f_is_zero(c_sub(t, px));
+        fp28_mul(t, c_neg(valid_unpark(park, l_, 1)), z3);
+        const bool ey = f_is_zero(c_sub(t, py));
+        st = ex && ey ? 0 : 2;
+    }
+    const uint32_t i_ = blockIdx.x * 64 + (uint32_t)l_;
+    if (i_ < n) status[i_] = (flags & 2) ? 0 : ((flags & 1) ? st : 1);
+}
+
+// two lanes per point: psi(P) == -[X] P  (src/g2.rs:166-170)
+__global__ void __launch_bounds__(64, 2) k_g2_valid_fast(const uint64_t* g2, const uint8_t* inf, uint32_t n, uint8_t* status) {
+    extern __shared__ int4 park[];          // values 0, 1: this lane's coefficient of the affine point; at LDS address 0
+    const int lane = threadIdx.x;
+    const uint32_t tid = blockIdx.x * 64 + lane;
+    const int c = (int)(tid & 1);
+    uint32_t i = tid >> 1;
+    const bool live = i < n;
+    if (!live) i = n - 1;
+    const bool is_inf = inf && inf[i];
+    F2 f{c};
+    bool on;
+    G2C r;
+    {
+        Fp28 x, y;
+        fp28_from_wire(x, g2 + 24 * (size_t)i + 6 * c);
+        fp28_from_wire(y, g2 + 24 * (size_t)i + 12 + 6 * c);
+        Fp28 lhs = f.sqr(y);
+        Fp28 rhs = c_add(f.mul(f.sqr(x), x), f_const(K28_B));     // b' = 4 (1 + u): both coefficients are 4
+        on = f.is_zero(c_sub(lhs, rhs));
+        valid_park(park, lane, 0, x);
+        valid_park(park, lane, 1, y);
+        r.x = x;
+        r.y = y;
+        r.z = f.one();
+    }
+    if (!__any(on && !is_inf)) {
+        if (live && c == 0) status[i] = is_inf ? 0 : 1;
+        return;
+    }
+#define ZKP_G2_STEP(BLOCK)                                                                                                               \
+    do {                                                                                                                                 \
+        constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};                                                                                     \
+        asm volatile(BLOCK                                                                                                               \
+                     : ZKP_G2_STEP_IO(r.x.l, r.y.l, r.z.l)                                                                               \
+                     : [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]),            \
+                       [p6] "s"(PL[6]), [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]),        \
+                       [p12] "s"(PL[12]), [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)                                                      \
+                     : ZKP_G2_STEP_CLOBBERS);                                                                                            \
+    } while (0)
+    const uint64_t xs = 0xd201000000010000ULL;
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+        ZKP_G2_STEP(ZKP_G2_DBL_ASM);
+        if ((xs >> b) & 1) ZKP_G2_STEP(ZKP_G2_MADD_ASM);
+    }
+    uint8_t st;
+    JacP p{r.x, r.y, r.z};
+    if (f.is_zero(p.z)) {
+        st = VALID_REDO;
+    } else {
+        Fp28 x = valid_unpark(park, lane, 0), y = valid_unpark(park, lane, 1);
+        // psi(P) = (conj(x) PSI_X, conj(y) PSI_Y); compare [X] P with (psi_x, -psi_y)
+        Fp28 cx = c ? c_neg(x) : x, cy = c ? c_neg(y) : y;
+        Fp28 kx = f_const(c ? K28_PSI_X_1 : K28_PSI_X_0), ky = f_const(c ? K28_PSI_Y_1 : K28_PSI_Y_0);
+        Fp28 qx = f.mul(cx, kx), qy = f.mul(cy, ky);
+        st = jac_eq_affine(f, p, qx, c_neg(qy)) ? 0 : 2;
+    }
+    if (live && c == 0) status[i] = is_inf ? 0 : (on ? st : 1);
+}
+#endif
 
 // a^(p-2) (Fermat; reference src/fp.rs:307-319); a == 0 gives 0.  Kept as the cross-check of f_inv (ZKP_INV_FERMAT).
 __device__ __forceinline__ Fp28 f_inv_fermat(const Fp28& a) {
@@ -2407,14 +2560,37 @@ hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, hip
     return hipEventElapsedTime(ms, e0, e1);
 }
 
+// ZKP_VALID_GENERIC=1 (environment, read once): the compiled kernels alone, the round-3 path - the A/B baseline and the cross-check
+static bool valid_generic_only() {
+    static const bool v = getenv("ZKP_VALID_GENERIC") && atoi(getenv("ZKP_VALID_GENERIC")) != 0;
+    return v;
+}
 hipError_t coop_g1_valid(const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_g1_valid28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, inf, (uint32_t)n, status);
+#if ZKP_VALID_ASM
+    if (!valid_generic_only()) {
+        hipLaunchKernelGGL(k_g1_valid_fast, dim3((unsigned)((n + 63) / 64)), dim3(64), 3 * 4 * 64 * sizeof(int4), s, g1, inf, (uint32_t)n, status);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_g1_valid28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, inf, (uint32_t)n, status, 1);
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(k_g1_valid28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, inf, (uint32_t)n, status, 0);
     return hipGetLastError();
 }
 hipError_t coop_g2_valid(const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_g2_valid28, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, g2, inf, (uint32_t)n, status);
+#if ZKP_VALID_ASM
+    if (!valid_generic_only()) {
+        hipLaunchKernelGGL(k_g2_valid_fast, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 2 * 4 * 64 * sizeof(int4), s, g2, inf, (uint32_t)n, status);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_g2_valid28, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, g2, inf, (uint32_t)n, status, 1);
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(k_g2_valid28, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, g2, inf, (uint32_t)n, status, 0);
     return hipGetLastError();
 }
 
