@@ -317,7 +317,8 @@ int zkp_clock_probe_dev(zkp_ctx* ctx, void* stream, unsigned spin_us, void* d_ou
 /* diagnostic: time one synthetic step program of the cooperative interpreter (which: 0 T=1, 1 T=3,
  * 2 T=3+epilogue, 3 T=6, 4 T=12, 5 LIN, 6 / 7 cyclotomic squaring without / with companion slots, 8 spill + fill;
  * 9: 400 compressed squarings of k_ksq; 10: the line precomputation k_prep_lines of n pairs; 11: the one-pair Miller
- * program over the line stream that 10 left behind - n at most one chunk, 65536 by default) over n checks, on ctx's own
+ * program over the line stream that 10 left behind - n at most one chunk, 65536 by default; 15: like 10 with the upstream-shaped
+ * lines of multi_miller_loop(), k_prep_lines<false>) over n checks, on ctx's own
  * stream with its own events; used by tools/ and by bench.py's per-kernel roofline split. */
 int zkp_time_coop_step(zkp_ctx* ctx, int which, size_t n, float* ms);
 

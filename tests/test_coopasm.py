@@ -130,11 +130,13 @@ def _resolved_rows(st, S, SC):
             rows[t][lig] = (addr(a1), addr(b1), addr(a2) | (addr(b2) << 16))
             f1 |= (int(neg) << t) | (int(da) << (12 + t))
             f2 |= (int(asub) << t) | (int(bsub) << (12 + t))
-        rows[T][lig] = (f1, f2, 0)
+        # the flag row also carries the step's store words: LDS byte address of the result slot and of its companion slot (-1: none)
+        sd = st.get("sd")
+        rows[T][lig] = (f1, f2, addr(ln["dst"]) if ln is not None else 0xffffffff, addr(sd[lig]) if (sd and ln is not None) else 0xffffffff)
     return rows, SG
 
 
-def _run_mulacc_block(g, out, st, slots, S, SC):
+def _run_mulacc_block(g, out, st, slots, S, SC, active_mask=0xfff):
     """execute the generated block for one MULACC step on 12 lanes; slots: slot number -> 14 limbs (constants included)"""
     rows, SG = _resolved_rows(st, S, SC)
     PS = SC + 5 * SG
@@ -151,15 +153,18 @@ def _run_mulacc_block(g, out, st, slots, S, SC):
         if any(x[7] for x in ts):
             hdr1 |= 1 << (16 + t)
     subst = _subst()
-    subst.update({"rt": "s[100:101]", "T": "s102", "h1": "s103", "h3": "s104", "lane16": "v1", "ps1": PS * 16, "ps2": PS * 32, "ps3": PS * 48, "row": 1024})
+    hdr1 |= int(bool(st["epi"])) | (int(bool(st.get("sd"))) << 1)
+    subst.update({"rt": "s[100:101]", "T": "s102", "h1": "s103", "h3": "s104", "lane16": "v1", "ps1": PS * 16, "ps2": PS * 32, "ps3": PS * 48, "row": 1024,
+                  "act": "s[106:107]", "nost": "s108"})
     emu = asmemu.Emu(lanes=12, subst=subst)
     base = 0x40000
     emu.s[100], emu.s[101], emu.s[102], emu.s[103], emu.s[104] = base, 0, T, hdr1, hdr3
+    emu.s[106], emu.s[107], emu.s[108] = active_mask, 0, int(bool(st["epi"]))
     emu.v[1] = [16 * lane for lane in range(12)]
     for r, row in enumerate(rows):
         for lane, ent in enumerate(row):
             for k in range(4):
-                emu.mem[base + 1024 * r + 16 * lane + 4 * k] = (ent[k] if k < 3 else 0) & asmemu.M32
+                emu.mem[base + 1024 * r + 16 * lane + 4 * k] = (ent[k] if k < len(ent) else 0) & asmemu.M32
     for extra in range(2):       # the block reads one row past the flag row's predecessor ahead of itself (the table is padded)
         for lane in range(12):
             for k in range(4):
@@ -194,6 +199,24 @@ def _check_program(builder, S, SC, em, max_steps=None):
                             col[i + j] += a[i] * b[j]
                 assert got[lig] == cg.acc_reduce(col), (pc, lig)
             done += 1
+            em.run([st])
+            # a step without epilogue stores from inside the block: the result slot and (companion steps) the companion slot of every
+            # lane hold what the emulator's step leaves there; an epilogue step stores nothing (the compiled code behind the block does)
+            PS = SC + 5 * (S + ((4 - S % 8) + 8) % 8)
+
+            def lds_slot(slot):
+                idx = SC + slot
+                return [asmemu.s32(emu.lds.get(16 * idx + (i // 4) * PS * 16 + 4 * (i % 4), 0)) for i in range(NL)]
+
+            for lig, ln in enumerate(st["lanes"]):
+                if st["epi"]:
+                    assert lds_slot(ln["dst"]) != got[lig] or not any(got[lig]), (pc, lig, "an epilogue step must not store from the block")
+                else:
+                    assert lds_slot(ln["dst"]) == list(em.slot[ln["dst"]]) == got[lig], (pc, lig, "result store")
+                    if st.get("sd"):
+                        assert lds_slot(st["sd"][lig]) == list(em.slot[st["sd"][lig]]), (pc, lig, "companion store")
+            pc += 1
+            continue
         em.run([st]) if st["op"] not in (cg.OP_LOOP, cg.OP_ENDLOOP) else None
         if st["op"] == cg.OP_LOOP:
             loop_start, loop_left = pc + 1, min(st["n"], 2)      # two iterations of a loop are enough here

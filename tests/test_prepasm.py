@@ -191,6 +191,97 @@ def test_addition_step_block_equals_the_formulas():
                 assert cg.from_mont(l) == want[c], (trial, k, c)
 
 
+def test_jacobian_doubling_step_equals_alg26_of_the_model():
+    """the doubling step of k_prep_lines<false> (prepasm.generate_jac): new point and the three stored line records against the
+    LITERAL Alg. 26 of the big-integer model (bls12_381_model.doubling_step, which the oracle-pinned Miller value is built from),
+    chained over three steps so that a step runs on what the previous one left (normalised X', Z')"""
+    import bls12_381_model as m
+    rng = random.Random(2026)
+    g = prepasm.generate_jac()
+    assert g.vend <= 256
+    q = m.g2_mul(m.G2_GEN, rng.randrange(2, 1 << 60))
+    r = (q[0], q[1], (1, 0))
+    xP, yP = rng.randrange(P), rng.randrange(P)
+    emu = asmemu.Emu(lanes=2, subst=_subst())
+    for c in range(2):
+        for base, val in ((g.X, r[0]), (g.Y, r[1]), (g.W, r[2])):
+            for i, x in enumerate(cg.mont(val[c])):
+                emu.v.setdefault(base + i, [None, None])[c] = x & asmemu.M32
+    nc = 7
+    emu.s[110] = 2 * nc * 64
+    emu.s[112], emu.s[113] = 0xffffffff, 0xffffffff
+    emu.s[115] = 0
+    emu.v[1] = [0, nc * 64]
+    for v, val in ((0, xP), (1, yP)):
+        l = cg.mont(val)
+        for lane in range(2):
+            for i in range(16):
+                emu.lds[(v * 4 + i // 4) * 1024 + 16 * lane + 4 * (i % 4)] = (l[i] if i < NL else 0) & asmemu.M32
+    for step in range(3):
+        emu.s[114] = 0x100000 * (step + 1)
+        emu.run(g.lines)
+        assert emu.exec == 3
+        r, (c0, c1, c2) = m.doubling_step(r)
+        for base, want, k in ((g.X, r[0], 2.2), (g.Y, r[1], 1.06), (g.W, r[2], 2.2)):
+            for c in range(2):
+                l = [asmemu.s32(emu.v[base + i][c]) for i in range(NL)]
+                assert all(abs(x) <= (1 << 27) + 16 for x in l[:NL - 1]) and abs(cg.limbs_value(l)) < k * P
+                assert cg.from_mont(l) == want[c], (step, base, c)
+        recs = (c2, ((c1[0] * xP) % P, (c1[1] * xP) % P), ((c0[0] * yP) % P, (c0[1] * yP) % P))     # records 0, 2, 4 (+ c)
+        for k, want in enumerate(recs):
+            for c in range(2):
+                addr = 0x100000 * (step + 1) + (2 * k + c) * nc * 64
+                l = [asmemu.s32(emu.mem[addr + 4 * i]) for i in range(NL)]
+                assert emu.mem[addr + 56] == 0 and emu.mem[addr + 60] == 0
+                assert all(abs(x) <= (1 << 27) + 16 for x in l[:NL - 1]) and abs(cg.limbs_value(l)) < 1.06 * P
+                assert cg.from_mont(l) == want[c], (step, k, c)
+
+
+def test_jacobian_addition_step_equals_alg27_of_the_model():
+    """the mixed-addition step of k_prep_lines<false> (prepasm.generate_jac_add) against the literal Alg. 27 of the model, behind
+    two asm doublings (so that it runs on what a doubling leaves)"""
+    import bls12_381_model as m
+    rng = random.Random(427)
+    gd, ga = prepasm.generate_jac(), prepasm.generate_jac_add()
+    assert ga.vend <= 256
+    q = m.g2_mul(m.G2_GEN, rng.randrange(2, 1 << 60))
+    r = (q[0], q[1], (1, 0))
+    xP, yP = rng.randrange(P), rng.randrange(P)
+    emu = asmemu.Emu(lanes=2, subst=_subst())
+    for c in range(2):
+        for base, val in ((gd.X, r[0]), (gd.Y, r[1]), (gd.W, r[2])):
+            for i, x in enumerate(cg.mont(val[c])):
+                emu.v.setdefault(base + i, [None, None])[c] = x & asmemu.M32
+    nc = 3
+    emu.s[110] = 2 * nc * 64
+    emu.s[112], emu.s[113] = 0xffffffff, 0xffffffff
+    emu.s[115] = 0
+    emu.v[1] = [0, nc * 64]
+    for v, val in ((0, (xP, xP)), (1, (yP, yP)), (2, q[0]), (3, q[1])):
+        for lane in range(2):
+            l = cg.mont(val[lane])
+            for i in range(16):
+                emu.lds[(v * 4 + i // 4) * 1024 + 16 * lane + 4 * (i % 4)] = (l[i] if i < NL else 0) & asmemu.M32
+    for step, kind in enumerate("ddadda"):
+        emu.s[114] = 0x100000 * (step + 1)
+        emu.run(gd.lines if kind == "d" else ga.lines)
+        assert emu.exec == 3
+        r, (c0, c1, c2) = m.doubling_step(r) if kind == "d" else m.addition_step(r, q)
+        for base, want, k in ((gd.X, r[0], 2.2), (gd.Y, r[1], 1.06), (gd.W, r[2], 2.2)):
+            for c in range(2):
+                l = [asmemu.s32(emu.v[base + i][c]) for i in range(NL)]
+                assert all(abs(x) <= (1 << 27) + 16 for x in l[:NL - 1]) and abs(cg.limbs_value(l)) < k * P
+                assert cg.from_mont(l) == want[c], (step, kind, base, c)
+        recs = (c2, ((c1[0] * xP) % P, (c1[1] * xP) % P), ((c0[0] * yP) % P, (c0[1] * yP) % P))
+        for k, want in enumerate(recs):
+            for c in range(2):
+                addr = 0x100000 * (step + 1) + (2 * k + c) * nc * 64
+                l = [asmemu.s32(emu.mem[addr + 4 * i]) for i in range(NL)]
+                assert emu.mem[addr + 56] == 0 and emu.mem[addr + 60] == 0
+                assert all(abs(x) <= (1 << 27) + 16 for x in l[:NL - 1]) and abs(cg.limbs_value(l)) < 1.06 * P
+                assert cg.from_mont(l) == want[c], (step, kind, k, c)
+
+
 def test_line_stores_obey_the_lane_mask():
     """a lane that the store mask excludes (a pair with an infinity, a lane behind the last pair) computes but stores nothing"""
     rng = random.Random(7)

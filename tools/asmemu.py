@@ -192,11 +192,28 @@ class Emu:
         val = ((1 << 64) - 1 if self.exec == (1 << self.n) - 1 else self.exec) if a[1] == "exec" else self.rd(a[1], 0)
         self.s[lo], self.s[lo + 1] = val & M32, (val >> 32) & M32
 
+    def _rd64(self, x):
+        x = x.strip()
+        if x == "vcc":
+            return self.vcc
+        if x == "exec":
+            return self.exec
+        return self.rd(x, 0)
+
     def op_s_and_b64(self, a, m):
-        lo = int(re.match(r"s\[(\d+):", a[0]).group(1))
-        val = self.rd(a[1], 0) & self.rd(a[2], 0)
-        self.s[lo], self.s[lo + 1] = val & M32, (val >> 32) & M32
+        val = self._rd64(a[1]) & self._rd64(a[2])
+        d = a[0].strip()
+        if d == "vcc":
+            self.vcc = val
+        elif d == "exec":
+            self.exec = val & ((1 << self.n) - 1)
+        else:
+            lo = int(re.match(r"s\[(\d+):", d).group(1))
+            self.s[lo], self.s[lo + 1] = val & M32, (val >> 32) & M32
         self.scc = int(val != 0)
+
+    def op_s_cmp_lg_u32(self, a, m):
+        self.scc = int(self._sr(a[0]) != self._sr(a[1]))
 
     def _sr(self, x):
         x = x.strip()
@@ -317,6 +334,13 @@ class Emu:
                     self.lds[addr + 4 * k] = (val >> (32 * k)) & M32
 
     # ---- vector
+    def op_v_cmp_ne_u32_e32(self, a, l, sl):     # vcc[lane] = src0 != src1 (lanes EXEC has switched off keep their bit clear)
+        assert a[0].strip() == "vcc"
+        if l == min(i for i in range(self.n) if (self.exec >> i) & 1):
+            self.vcc = 0
+        if (self.rd(a[1], l) & M32) != (self.rd(a[2], l) & M32):
+            self.vcc |= 1 << l
+
     def op_v_mov_b32(self, a, l, sl):
         self.wr(a[0], l, self.rd(a[1], sl))
 

@@ -62,6 +62,8 @@ class Asm:
         self.sX = s; s += 2           # temporaries
         self.sN = s; s += 2           # number of the next term (+ pad)
         self.sC = s; s += 2           # carry-out sink of the multiply-adds
+        self.sFR = s; s += 2          # address of the step's flag / store row (row T of the resolved table)
+        self.sEX = s; s += 2          # EXEC at entry
         self.send = s
 
     def e(self, s):
@@ -272,6 +274,7 @@ def generate(vb=8):
     g.e("s_mul_i32 s%d, %%[T], %%[row]" % g.sX)       # row: bytes per table row (64 lanes x 16 B x wavefronts per workgroup)
     g.e("s_add_u32 s%d, s%d, s%d" % (g.sX, g.sRT, g.sX))
     g.e("s_addc_u32 s%d, s%d, 0" % (g.sX + 1, g.sRT + 1))
+    g.e("s_mov_b64 s[%d:%d], s[%d:%d]" % (g.sFR, g.sFR + 1, g.sX, g.sX + 1))
     g.e("global_load_dwordx3 v[%d:%d], %%[lane16], s[%d:%d]" % (g.E, g.E + 2, g.sRT, g.sRT + 1))
     g.e("global_load_dwordx2 v[%d:%d], %%[lane16], s[%d:%d]" % (g.F, g.F + 1, g.sX, g.sX + 1))
     g.e("s_mov_b32 s%d, 0" % g.sT)
@@ -294,8 +297,48 @@ def generate(vb=8):
     g.e("s_cmp_lt_u32 s%d, %%[T]" % g.sT)
     g.e("s_cbranch_scc1 .Lmloop_%=")
     g.e(".Lmtail_%=:")
-    g.e("s_waitcnt vmcnt(0)")        # nothing of this block may still be in flight when the compiler's code resumes
+    g.e("s_waitcnt vmcnt(0)")
+    # the step's store words (z, w of the flag row; the flag words themselves are dead): LDS byte address of the result slot and of
+    # its companion slot, -1 where the lane stores nothing - requested here, they arrive behind the reduction
+    g.e("global_load_dwordx2 v[%d:%d], %%[lane16], s[%d:%d] offset:8" % (g.F, g.F + 1, g.sFR, g.sFR + 1))
     tail(g, out)
+    g.e("s_waitcnt vmcnt(0)")        # nothing of this block may still be in flight when the compiler's code resumes
+    # ---- round 4: the result store and the companion store of a step WITHOUT epilogue happen here (nost = 0), under the caller's
+    # active lanes: the compiled code behind the block (lane context, 14 DPP moves + 42 ALU of the companion forms, the copies out
+    # of the pinned registers) runs for the rare epilogue steps only
+    g.e("s_cmp_lg_u32 %[nost], 0")
+    g.e("s_cbranch_scc1 .Lmdone_%=")
+    g.e("s_mov_b64 s[%d:%d], exec" % (g.sEX, g.sEX + 1))
+    g.e("v_cmp_ne_u32_e32 vcc, -1, v%d" % g.F)
+    g.e("s_and_b64 vcc, vcc, %[act]")
+    g.e("s_and_b64 exec, vcc, s[%d:%d]" % (g.sEX, g.sEX + 1))
+
+    def st_rec(src, addr):
+        g.e("ds_write_b128 v%d, v[%d:%d]" % (addr, src, src + 3))
+        g.e("ds_write_b128 v%d, v[%d:%d] offset:%%[ps1]" % (addr, src + 4, src + 7))
+        g.e("ds_write_b128 v%d, v[%d:%d] offset:%%[ps2]" % (addr, src + 8, src + 11))
+        g.e("ds_write_b64 v%d, v[%d:%d] offset:%%[ps3]" % (addr, src + 12, src + 13))
+
+    st_rec(out, g.F)
+    g.e("s_mov_b64 exec, s[%d:%d]" % (g.sEX, g.sEX + 1))
+    g.e("s_bitcmp1_b32 %[h1], 1")
+    g.e("s_cbranch_scc0 .Lmdone_%=")
+    # companion slot: lanes 2j, 2j + 1 hold one Fp2 coefficient (x0, x1); the even lane keeps x0 + x1, the odd lane x0 - x1 =
+    # partner + s r with s r = r on even lanes, -r = (r xor -1) + 1 on odd lanes; the partner's r arrives inside the addition (DPP)
+    T = g.B[0]
+    g.e("v_bfe_u32 v%d, %%[lane16], 4, 1" % g.vm)
+    g.e("v_sub_u32 v%d, 0, v%d" % (g.vc, g.vm))
+    for i in range(NL):
+        g.e("v_xad_u32 v%d, v%d, v%d, v%d" % (T + i, out + i, g.vc, g.vm))
+    g.e("s_nop 1")
+    for i in range(NL):
+        g.e("v_add_u32_dpp v%d, v%d, v%d quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % (T + i, out + i, T + i))
+    g.e("v_cmp_ne_u32_e32 vcc, -1, v%d" % (g.F + 1))
+    g.e("s_and_b64 vcc, vcc, %[act]")
+    g.e("s_and_b64 exec, vcc, s[%d:%d]" % (g.sEX, g.sEX + 1))
+    st_rec(T, g.F + 1)
+    g.e("s_mov_b64 exec, s[%d:%d]" % (g.sEX, g.sEX + 1))
+    g.e(".Lmdone_%=:")
     g.e("s_waitcnt lgkmcnt(0)")
     return g, out
 
@@ -570,7 +613,7 @@ def write_inc(path, vb=8):
             f.write('    "%s\\n\\t" \\\n' % l)
         f.write('    ""\n')
         f.write("#define ZKP_MULACC_OUTS(r) " + ", ".join('"={v%d}"((r)[%d])' % (outs[i], i) for i in range(NL)) + "\n")
-        f.write("#define ZKP_MULACC_CLOBBERS " + ", ".join('"v%d"' % v for v in vclob) + ", " + ", ".join('"s%d"' % s for s in sclob) + ', "scc", "memory"\n')
+        f.write("#define ZKP_MULACC_CLOBBERS " + ", ".join('"v%d"' % v for v in vclob) + ", " + ", ".join('"s%d"' % s for s in sclob) + ', "vcc", "scc", "memory"\n')
         write_ksq(f)
     return g
 

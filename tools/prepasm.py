@@ -357,6 +357,149 @@ def generate_add(vb=6):
     return g
 
 
+def generate_jac(vb=6):
+    """The doubling step of k_prep_lines<false> - the lines zkp_multi_miller_loop_batch must return the value of - as one block:
+    the point in Jacobian coordinates as ePrint 2010/354 Alg. 26 walks it (zkp_coop.hip dbl_step; reference src/g2.rs:210-242 is the
+    same doubling) and the upstream-shaped line coefficients, every VALUE mod p the one Alg. 26 produces (the Miller value is
+    compared bit for bit with the oracle's), the route to it the cheapest this machine has:
+        B = Y^2, zz = Z^2, Z' = (Y + Z)^2 - B - zz,  M = 3 X^2 (straight out of the squaring's reduction),  S = (4X) B,
+        X' = M^2 - 2S,  Y' = M (S - X') - 8 B^2 (one lazy accumulation),
+        c0 yP = (2 Z' zz) yP  [record 4 + c],  c1 xP = (-2 M zz) xP  [record 2 + c],  c2 = 2 X M - 4 B = 6 X^3 - 4 Y^2  [record 0 + c]
+    (Alg. 26's tmp6 = (X + tmp4)^2 - tmp0 - tmp5 is 6 X^3, its tmp3 is S).  18 product blocks and 12 reductions per lane against the
+    16 + 13 of the literal algorithm on schoolbook blocks; X' and Z' leave normalised (one carry pass), nothing is renormalised
+    but the stored c2."""
+    g = Prep(vb)
+    X, Y, W = g.X, g.Y, g.W
+    V0, V1, V2, V3 = g.V
+    T0, T1, T2 = g.T
+    g.prologue()
+    g.sqr(V0, Y)                          # B
+    g.sqr(V1, W)                          # zz
+    g.add(T2, Y, W)
+    g.sqr(V2, T2, 2)
+    g.sub(V2, V2, V0)
+    g.sub(V2, V2, V1)
+    g.norm(V2)                            # Z' = 2 Y Z: limbs of one unit, |value| <= 2.2 p
+    # c0 yP = (2 Z' zz) yP -> record 4 + c
+    g.mul(V3, V2, V1, 1, 1)
+    g.shl(V3, V3, 1)
+    g.fmul(T2, V3, 1, 2)
+    g.store(T2, 4)
+    # M = 3 X^2
+    g.sqr_forms(X)
+    g.times3(T0, T0)
+    g.prod(T1, T0, True, 2, 6)
+    tail(g, V3)
+    # c1 xP = (-2 M zz) xP -> record 2 + c
+    g.mul(T2, V3, V1, 1, 1)
+    g.shl(T2, T2, 1)
+    g.neg(T2, T2)
+    g.fmul(T2, T2, 0, 2)
+    g.store(T2, 2)
+    # c2 = 2 X M - 4 B, renormalised -> record 0 + c   (zz is dead: its block holds 2X, then -B)
+    g.shl(V1, X, 1)
+    g.mul(T2, V1, V3, 2, 1)
+    g.neg(V1, V0)
+    for i in range(NL):
+        g.e("v_lshl_add_u32 v%d, v%d, 2, v%d" % (T2 + i, V1 + i, T2 + i))
+    g.vred(T2)
+    g.store(T2, 0)
+    # S = (4X) B
+    g.shl(V1, X, 2)
+    g.mul(V1, V1, V0, 4, 1)
+    # X' = M^2 - 2S
+    g.sqr(X, V3)
+    g.neg(T2, V1)
+    for i in range(NL):
+        g.e("v_lshl_add_u32 v%d, v%d, 1, v%d" % (X + i, T2 + i, X + i))
+    g.norm(X)
+    # Y' = M (S - X') - 8 B^2
+    g.sub(V1, V1, X)
+    g.mul_acc(V3, V1, True, 1, 2)
+    g.sqr_forms(V0)
+    g.norm(T1)
+    g.shl(T1, T1, 2)
+    g.neg(T1, T1)
+    g.shl(T0, T0, 1)
+    g.prod(T1, T0, False, 4, 4)
+    tail(g, Y)
+    g.mov(W, V2)
+    g.e("s_waitcnt vmcnt(0)")
+    return g
+
+
+def generate_jac_add(vb=6):
+    """The mixed-addition step of k_prep_lines<false>: ePrint 2010/354 Alg. 27 in VALUES (zkp_coop.hip add_step), Q = (qx, qy) parked
+    in LDS values 2, 3:
+        zz = Z^2, U2 = qx zz, S2' = (2 qy) Z zz, H = U2 - X, r = S2' - 2Y  [Alg. 27's t2, t6],  Z' = (2Z) H  [its nz],
+        HH = H^2, t5 = (2H)(2HH) = 4 H^3, t7 = (2X)(2HH) = 4 X H^2,  X' = r^2 - t5 - 2 t7,  Y' = r (t7 - X') - (2Y) t5,
+        c0 yP = (2 Z') yP [record 4 + c], c1 xP = (-2 r) xP [record 2 + c], c2 = r (2 qx) - (2 qy) Z' [record 0 + c, one reduction]
+    25 product blocks and 13 reductions per lane; X' leaves renormalised, Y' and Z' as reduced products."""
+    g = Prep(vb)
+    X, Y, W = g.X, g.Y, g.W
+    V0, V1, V2, V3 = g.V
+    T0, T1, T2 = g.T
+    QX, QY = 2, 3
+    g.prologue()
+    g.sqr(V0, W)                          # zz
+    g.mul(V1, W, V0, 1, 1)                # Z zz
+    g.park_read(V2, QX)
+    g.e("s_waitcnt lgkmcnt(0)")
+    g.mul(V0, V2, V0, 1, 1)               # U2
+    g.sub(V0, V0, X)                      # H (limbs 2 units)
+    g.park_read(V2, QY)
+    g.e("s_waitcnt lgkmcnt(0)")
+    g.shl(V2, V2, 1)
+    g.mul(V1, V2, V1, 2, 1)               # S2' = (2 qy) Z zz
+    g.shl(T2, Y, 1)
+    g.sub(V1, V1, T2)                     # r = S2' - 2Y (limbs 3 units, |value| <= 3.2 p)
+    g.norm(V1)
+    g.shl(W, W, 1)
+    g.mul(W, W, V0, 2, 2)                 # Z' = (2Z) H
+    # lines: c0 yP, c1 xP, c2
+    g.shl(T2, W, 1)
+    g.fmul(T2, T2, 1, 2)
+    g.store(T2, 4)
+    g.shl(T2, V1, 1)
+    g.neg(T2, T2)
+    g.fmul(T2, T2, 0, 2)
+    g.store(T2, 2)
+    g.park_read(V3, QX)
+    g.e("s_waitcnt lgkmcnt(0)")
+    g.shl(V3, V3, 1)
+    g.mul_acc(V1, V3, True, 1, 2)         # r (2 qx)
+    g.park_read(V3, QY)
+    g.e("s_waitcnt lgkmcnt(0)")
+    g.shl(V3, V3, 1)
+    g.neg(V3, V3)
+    g.mul_acc(V3, W, False, 2, 1)         # - (2 qy) Z'
+    tail(g, T2)
+    g.vred(T2)
+    g.store(T2, 0)
+    # the point
+    g.sqr(V2, V0, 2)                      # HH
+    g.shl(V2, V2, 1)                      # 2 HH
+    g.shl(V0, V0, 1)                      # 2 H (limbs 4 units)
+    g.mul(V0, V0, V2, 4, 2)               # t5 = 4 H^3
+    g.shl(V3, X, 1)
+    g.mul(V2, V3, V2, 2, 2)               # t7 = 4 X H^2
+    g.sqr(X, V1)                          # r^2
+    g.sub(X, X, V0)
+    g.neg(T2, V2)
+    for i in range(NL):
+        g.e("v_lshl_add_u32 v%d, v%d, 1, v%d" % (X + i, T2 + i, X + i))      # X' = r^2 - t5 - 2 t7
+    g.norm(X)
+    g.vred(X)
+    g.sub(V2, V2, X)                      # t7 - X'
+    g.mul_acc(V1, V2, True, 1, 2)
+    g.shl(Y, Y, 1)
+    g.neg(Y, Y)
+    g.mul_acc(Y, V0, False, 2, 1)
+    tail(g, Y)                            # Y' = r (t7 - X') - (2Y) t5
+    g.e("s_waitcnt vmcnt(0)")
+    return g
+
+
 def write_inc(path, vb=6):
     g = generate(vb)
     ga = generate_add(vb)
@@ -378,6 +521,19 @@ def write_inc(path, vb=6):
                 % sum(1 for l in ga.lines if not l.endswith(":")))
         f.write("#define ZKP_PREP_ADD_ASM \\\n")
         for l in ga.lines:
+            f.write('    "%s\\n\\t" \\\n' % l)
+        f.write('    ""\n')
+        gj = generate_jac(vb)
+        f.write("// the Jacobian doubling step with the upstream-shaped lines (k_prep_lines<false>): %d instructions, the same operands and clobbers\n"
+                % sum(1 for l in gj.lines if not l.endswith(":")))
+        f.write("#define ZKP_PREP_JAC_DBL_ASM \\\n")
+        for l in gj.lines:
+            f.write('    "%s\\n\\t" \\\n' % l)
+        f.write('    ""\n')
+        gja = generate_jac_add(vb)
+        f.write("// ... and its mixed addition step (Alg. 27 in values): %d instructions\n" % sum(1 for l in gja.lines if not l.endswith(":")))
+        f.write("#define ZKP_PREP_JAC_ADD_ASM \\\n")
+        for l in gja.lines:
             f.write('    "%s\\n\\t" \\\n' % l)
         f.write('    ""\n')
         f.write("#define ZKP_PREP_DBL_CLOBBERS " + ", ".join('"v%d"' % v for v in range(g.V[0], g.vend)) + ", "

@@ -221,6 +221,11 @@ __global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
 
     for (int i = lane; i < (int)A.nconst * 4; i += 64 * WGW) lds[(i & 3) * PS + (i >> 2)] = A.consts[i];
     __syncthreads();
+#if ZKP_COOP_ASM
+    // the lanes that own a coefficient of a live check: wave-uniform (two SGPRs), the store mask of the asm MULACC block
+    ZKP_LANE_CTX();
+    const unsigned long long act_lanes = __ballot(active);
+#endif
 
     // the step headers are read-only and wave-uniform: through the constant address space they become scalar loads
     // (s_load_dwordx4 into SGPRs, scalar cache) instead of a vector load + readfirstlane per word
@@ -246,8 +251,11 @@ __global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             // one inline-asm block (tools/coopasm.py): term loop on two operand register sets with resolved per-lane LDS
             // addresses, Karatsuba fold, row-pipelined Montgomery reduction, limb extraction; the same integers as
             // acc_mul_k / acc_fold / acc_reduce of the C++ variant below
-            const uint32_t ew = tbl[off + T * LIG + lig];
             const uint4* rt = A.rtbl + (size_t)(off / LIG) * (64 * WGW);
+            // round 4: a step without epilogue stores its result and its companion form from inside the block (resolved
+            // addresses in the flag row of the table, the active lanes as a mask); with several wavefronts per workgroup the
+            // stores must wait for the workgroup's fence, so they stay behind the block
+            const uint32_t nost = (h1 & 1u) | (WGW > 1 ? 1u : 0u);
             int32_t r[NL];
             {
                 static_assert(NL == 14, "the generated block is for 14 limbs");
@@ -255,13 +263,16 @@ __global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 asm volatile(ZKP_MULACC_ASM
                              : ZKP_MULACC_OUTS(r)
                              : [rt] "s"(rt), [T] "s"(T), [h1] "s"(h1), [h3] "s"(h3), [lane16] "v"(lane * 16),   // (rematerialised from the lane number: not a live value)
+                               [act] "s"(act_lanes), [nost] "s"(nost),
                                [ps1] "i"(PS * 16), [ps2] "i"(PS * 32), [ps3] "i"(PS * 48), [row] "i"(1024 * WGW),
                                [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]), [p6] "s"(PL[6]),
                                [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]), [p12] "s"(PL[12]),
                                [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)
                              : ZKP_MULACC_CLOBBERS);
             }
+            if (!nost) { pc++; continue; }
             ZKP_LANE_CTX();
+            const uint32_t ew = tbl[off + T * LIG + lig];
 #else
             Acc acc;
             acc_zero(acc);
@@ -927,7 +938,7 @@ struct G2C { Fp28 x, y, z; };   // this lane's coefficient of the three Jacobian
 //   * the one-pass normalisation adds 2^27 to a limb: L <= 14;  the value renormalisation subtracts q p first, q <= |v| / p + 1/2,
 //     p's balanced limbs are at most 2^27: L + q + 1 <= 15.
 template <int L, int LO, int HI> struct Bd { Fp28 v; };
-constexpr int bd_k(int lo, int hi) { return -lo > hi ? -lo : hi; }
+[[maybe_unused]] constexpr int bd_k(int lo, int hi) { return -lo > hi ? -lo : hi; }
 typedef Bd<1, -4, 68> BdRed;     // a reduced product
 typedef Bd<1, -33, 33> BdVred;   // after the value renormalisation (|v| <= 0.51 p)
 template <int L1, int A1, int B1, int L2, int A2, int B2>
@@ -1042,7 +1053,7 @@ __device__ __forceinline__ void dbl_step(G2C& r, int c, S0&& sink_l0, S1&& sink_
     r.z = bd_vred(nz).v;
 }
 // ePrint 2010/354 Alg. 27
-__device__ __forceinline__ void add_step(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, const Fp28& qx, const Fp28& qy, int c) {
+[[maybe_unused]] __device__ __forceinline__ void add_step(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, const Fp28& qx, const Fp28& qy, int c) {
     Fp28 zsq = c_sqr(r.z, c);
     Fp28 ysq = c_sqr(qy, c);
     Fp28 t0 = c_mul(zsq, qx, c);
@@ -1126,7 +1137,7 @@ __device__ __forceinline__ void dbl_step_cln(G2C& r, int c, S0&& sink_l0, S1&& s
 //   th = 2 Y - y2 W, la = 2 X - x2 W, C = th^2, D = la^2, E = la D, F = W C, G = 2 X D, H = E + F - 2 G,
 //   X' = la H, Y' = th (G - H) - 2 Y E, W' = 2 W E        line (times 2): la yP - th xP + (th x2 - la y2)
 // Five of the 68 steps: written with normalising additions, no bound bookkeeping beyond |v| < 8 p at every product.
-__device__ __forceinline__ void add_step_cln(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, const Fp28& qx, const Fp28& qy, int c) {
+[[maybe_unused]] __device__ __forceinline__ void add_step_cln(Fp28& l0, Fp28& l1, Fp28& l2, G2C& r, const Fp28& qx, const Fp28& qy, int c) {
     Fp28 th = c_sub(c_dbl(r.y), c_mul(qy, r.z, c));
     Fp28 la = c_sub(c_dbl(r.x), c_mul(qx, r.z, c));
     vred(th.l); vred(la.l);
@@ -1176,7 +1187,7 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
         park[(v * 4 + 2) * 64 + lane] = make_int4(x.l[8], x.l[9], x.l[10], x.l[11]);
         park[(v * 4 + 3) * 64 + lane] = make_int4(x.l[12], x.l[13], 0, 0);
     };
-    auto park_ld = [&](int v) -> Fp28 {
+    [[maybe_unused]] auto park_ld = [&](int v) -> Fp28 {
         asm volatile("" ::: "memory");   // keep the load at its use (no hoisting out of the step loop)
         const int4 v0 = park[(v * 4 + 0) * 64 + lane], v1 = park[(v * 4 + 1) * 64 + lane], v2 = park[(v * 4 + 2) * 64 + lane],
                    v3 = park[(v * 4 + 3) * 64 + lane];
@@ -1202,6 +1213,7 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
     uint32_t step = 0;
     // stream order (c2, c1 * xP, c0 * yP) = the (c0, c1, c4) operands of mul_by_014; a pair with an infinity streams
     // the neutral line (1, 0, 0)
+#if !ZKP_PREP_ASM
     auto put = [&](uint32_t e, const Fp28& v) {
         if (!live_lane) return;
         if (dead) {      // a branch, not selects: as selects the limbs of ONE stay in (spilled) registers for the whole kernel
@@ -1216,10 +1228,10 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
     auto sink_l0 = [&](const Fp28& l0) { put(4, f_mul_v(l0, park_ld(PY))); };
     auto sink_l1 = [&](const Fp28& l1) { put(2, f_mul_v(l1, park_ld(PX))); };
     auto sink_l2 = [&](Fp28 l2) { vred(l2.l); put(0, l2); };
-#if ZKP_PREP_ASM
+#else
     // the asm steps store the lines of live pairs without an infinity only; a pair with an infinity streams the neutral line
     // (1, 0, 0) at every step - written here, ahead of the loop, so that none of this is alive across the blocks
-    if (CLN && live_lane && dead) {
+    if (live_lane && dead) {
         Fp28 o;
         for (uint32_t st = 0; st < (uint32_t)NLINES; st++) {
             for (uint32_t e = 0; e < 6; e += 2) {
@@ -1254,17 +1266,16 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
                          : ZKP_PREP_DBL_CLOBBERS);                                                                                        \
         } while (0)
         static_assert(NL == 14, "the generated blocks are for 14 limbs");
-        if (CLN) ZKP_PREP_STEP_ASM(ZKP_PREP_DBL_ASM); else dbl_step(r, c, sink_l0, sink_l1, sink_l2);
+        // <false>: the Jacobian doubling with the upstream-shaped lines (round 4: generate_jac, 18 Karatsuba blocks + 12 reductions)
+        if (CLN) ZKP_PREP_STEP_ASM(ZKP_PREP_DBL_ASM); else ZKP_PREP_STEP_ASM(ZKP_PREP_JAC_DBL_ASM);
 #else
         if (CLN) dbl_step_cln(r, c, sink_l0, sink_l1, sink_l2); else dbl_step(r, c, sink_l0, sink_l1, sink_l2);
 #endif
         step++;
         if ((xs >> b) & 1) {
 #if ZKP_PREP_ASM
-            if (CLN) {
-                ZKP_PREP_STEP_ASM(ZKP_PREP_ADD_ASM);
-            } else
-#endif
+            if (CLN) ZKP_PREP_STEP_ASM(ZKP_PREP_ADD_ASM); else ZKP_PREP_STEP_ASM(ZKP_PREP_JAC_ADD_ASM);
+#else
             {
                 Fp28 l0, l1, l2;
                 if (CLN) add_step_cln(l0, l1, l2, r, park_ld(QX), park_ld(QY), c); else add_step(l0, l1, l2, r, park_ld(QX), park_ld(QY), c);
@@ -1272,6 +1283,7 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
                 sink_l1(l1);
                 sink_l0(l0);
             }
+#endif
             step++;
         }
     }
@@ -2093,7 +2105,13 @@ static void coop_resolve_table(const ZkpProgDesc& p, std::vector<uint4>& rt) {
                 f1 |= ((w >> 30) & 1) << t | ((w >> 31) & 1) << (12 + t);
                 f2 |= ((w >> 28) & 1) << t | ((w >> 29) & 1) << (12 + t);
             }
-            rt[(off / LIG + T) * RL + lane] = make_uint4(f1, f2, 0, 0);
+            // z, w: LDS byte address of the step's result slot / companion slot for this lane, -1 where it stores nothing
+            // (a padding lane of the step, lanes 60..63 of a wavefront)
+            const uint32_t ew = p.tbl[off + T * LIG + lig];
+            const bool owner = WGW > 1 || g0 < GROUPS;
+            const uint32_t dst = (owner && ((ew >> 7) & 1)) ? addr(ew & 63, grp) : 0xffffffffu;
+            const uint32_t sd = (owner && ((ew >> 29) & 1)) ? addr((ew >> 23) & 63, grp) : 0xffffffffu;
+            rt[(off / LIG + T) * RL + lane] = make_uint4(f1, f2, dst, sd);
         }
     }
 }
@@ -2535,18 +2553,18 @@ hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, hip
     static const int ids[9] = {ZKP_PROG_TIME_T1, ZKP_PROG_TIME_T3, ZKP_PROG_TIME_T3E, ZKP_PROG_TIME_T6, ZKP_PROG_TIME_T12, ZKP_PROG_TIME_LIN,
                                ZKP_PROG_TIME_CYC, ZKP_PROG_TIME_CYCSD, ZKP_PROG_TIME_FILL};
     static const int ids2[3] = {ZKP_PROG_TIME_T6S, ZKP_PROG_TIME_T12S, ZKP_PROG_TIME_T12B};   // which 12..14: one-slot / B-two-slot operand forms
-    if (which < 0 || which > 14 || !n || n > 0x7fffffffu || ((which == 10 || which == 11) && n > d->chunk)) return hipErrorInvalidValue;
+    if (which < 0 || which > 15 || !n || n > 0x7fffffffu || ((which == 10 || which == 11 || which == 15) && n > d->chunk)) return hipErrorInvalidValue;
     hipError_t e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, (size_t)ST_SIZE * n * 64);
     if (e != hipSuccess) return e;
-    if ((which == 10 || which == 11) && (e = ensure_buf(&d->pipe[0].lines, &d->pipe[0].lines_bytes, (size_t)NLINES * 6 * n * 64)) != hipSuccess) return e;
+    if ((which == 10 || which == 11 || which == 15) && (e = ensure_buf(&d->pipe[0].lines, &d->pipe[0].lines_bytes, (size_t)NLINES * 6 * n * 64)) != hipSuccess) return e;
     CoopPipe v = d->pipe[0];
     v.stream = s;
     auto once = [&]() -> hipError_t {
         if (which == 9) return run_ksq(s, v.state, (uint32_t)n, (uint32_t)n, 0, 12, 400, 0);   // timing run: no snapshots (a mask needs nsq <= 64)
-        if (which >= 12) return run_prog(d, &v, ids2[which - 12], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
-        if (which == 10) {
+        if (which >= 12 && which <= 14) return run_prog(d, &v, ids2[which - 12], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
+        if (which == 10 || which == 15) {                          // 15: the upstream-shaped lines (k_prep_lines<false>)
             const uint64_t* zero = (const uint64_t*)v.state;      // 36 u64 of zeros per pair: the state buffer is far larger
-            return prep(&v, zero, zero + 12 * n, nullptr, nullptr, 0, (uint32_t)n, 1, 0, 1, true);
+            return prep(&v, zero, zero + 12 * n, nullptr, nullptr, 0, (uint32_t)n, 1, 0, 1, which == 10);
         }
         if (which == 11) return run_prog(d, &v, ZKP_PROG_MILLER1_STATE, (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
         return run_prog(d, &v, ids[which], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
