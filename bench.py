@@ -174,6 +174,46 @@ def main():
         mine = torch.tensor([own_kernel_ms, coll_ms, 1e3 * dt_rank / args.steps, float(n)], dtype=torch.float64)
         rank_diag = zdist.gather_rows(mine, dev)
 
+    # ---- the same collective through the C ABI (zkp_comm_init_rank / zkp_and_allreduce_dev / zkp_pairing_check_batch_allreduce_dev:
+    # what a Rust / C host runs, librccl linked into libzkp_pairings.so), outside the timed region and behind a watchdog: a hang or
+    # an error here costs the line one field, never the measurement above
+    abi_coll, abi_hung = None, False
+    if world > 1 and backend == "nccl" and not shared_gpu:
+        import threading
+        uid = [z.PairingEngine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0, device=dev)
+        res = {}
+
+        def abi_probe():
+            try:
+                torch.cuda.set_device(dev)
+                eng.comm_init_rank(world, rank, uid[0])
+                f = torch.ones(1, dtype=torch.int32, device=dev)
+                eng.and_allreduce(f)
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                for _ in range(8):
+                    eng.and_allreduce(f)
+                torch.cuda.synchronize()
+                res["allreduce_ms"] = (time.perf_counter() - tc) * 1e3 / 8
+                m = min(n, 4096)
+                okb, fl = eng.pairing_check_allreduce(g1[:m].contiguous(), g2[:m].contiguous(), 1)
+                torch.cuda.synchronize()
+                res["check_flag"] = int(fl.item())          # random pairs: never the identity -> 0 on every rank
+                res["and_of_ones"] = int(f.item())
+                eng.comm_destroy()
+                res["ok"] = res["check_flag"] == 0 and res["and_of_ones"] == 1
+            except Exception as ex:      # reported in the line
+                res["ok"], res["error"] = False, repr(ex)
+
+        th = threading.Thread(target=abi_probe, daemon=True)
+        th.start()
+        th.join(90)
+        abi_hung = th.is_alive()
+        abi_coll = {"ok": False, "error": "no answer within 90 s"} if abi_hung else dict(res)
+        abi_coll["what"] = ("the path's one collective through the C ABI: zkp_comm_init_rank on %d ranks, 8 x zkp_and_allreduce_dev (mean ms), one "
+                            "zkp_pairing_check_batch_allreduce_dev of 4096 pairs per rank; rank 0's view" % world)
+
     line = None
     if rank == 0:
         # ---- everything below is measurement bookkeeping outside the timed region
@@ -212,11 +252,24 @@ def main():
             tk = ticks.cpu().numpy()
             sustained_ghz = float(tk[0]) / float(tk[1]) * wall_khz * 1e3 / 1e9 if tk[1] > 0 else None
 
+        # what the kernels EXECUTE (multiply-add instructions of the generated asm blocks and step programs x lanes issued, idle
+        # lanes included), beside the algorithmic count the roofline fraction is priced on
+        executed = None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import executed_macs
+            em = executed_macs.per_pairing()
+            executed = {"total": em["total"], "per_kernel": {k: v for k, v in em.items() if k != "total"},
+                        "source": "tools/executed_macs.py: v_mad_[iu]64_[iu]32 instructions of the generated asm blocks, T x 147 + 196 per MULACC step of "
+                                  "the step programs, x lanes issued (a wavefront issues for all 64 lanes); the compiled decompression / inversion "
+                                  "kernels are estimates from their source"}
+        except Exception as ex:      # the counter needs tools/ and tests/golden/ of the repository
+            executed = {"total": None, "error": repr(ex)}
         value = global_pairs * args.steps / dt
         achieved = (n * MACS_PER_PAIRING) / (kern_ms * 1e-3)
         phase = lambda fpm, ms: ((n * fpm * MACS_PER_FPMUL) / (ms * 1e-3) / PEAK_MACS) if ms else None
         traffic = traffic_src = None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             tpath = os.path.join(ROOT, "profiles", rnd, "pmc", "traffic.json")
             if os.path.exists(tpath) and args.kernel in ("auto", "coop"):
                 with open(tpath) as tf:   # rocprofv3 PMC passes over one 2^20-pair pass, gfx950-corrected (tools/pmc_traffic.py); linear in n
@@ -242,6 +295,8 @@ def main():
             secondary["config4_three_pair_checks"] = {
                 "checks": nc4, "ms": c4_ms, "checks_per_s": nc4 / c4_ms * 1e3, "fp_mul_equivalents_per_check": FPMUL_CHECK3,
                 "frac": nc4 * FPMUL_CHECK3 * MACS_PER_FPMUL / (c4_ms * 1e-3) / PEAK_MACS,
+                "macs_source": "SURVEY.md 8(d): Miller(3 pairs) 21,492 + final exponentiation 11,729 Fp-mul-equivalents x 300; "
+                               "recomputable from profiles/r04/workloads_a.json (roofline.config4_three_pair_checks)",
                 "what": "multi-Miller loop over 3 pairs (miller3 program: shared squarings) + ONE final exponentiation + identity flag per check; "
                         "the timed batch's points regrouped in threes (the rate does not depend on the flags' values)"}
             v1_ms = wall_ms(lambda: eng.g1_is_valid(g1))       # config 5: on-curve + subgroup check of 2^20 G1 and 2^20 G2 points
@@ -249,11 +304,41 @@ def main():
             secondary["config5_validity"] = {
                 "points": n,
                 "g1": {"ms": v1_ms, "points_per_s": n / v1_ms * 1e3, "fp_mul_equivalents_per_point": FPMUL_G1_VALID,
-                       "frac": n * FPMUL_G1_VALID * MACS_PER_FPMUL / (v1_ms * 1e-3) / PEAK_MACS, "kernel": "k_g1_valid28"},
+                       "frac": n * FPMUL_G1_VALID * MACS_PER_FPMUL / (v1_ms * 1e-3) / PEAK_MACS,
+                       "kernel": "k_g1_valid_fast (asm doubling / addition steps, 3 waves per SIMD) + k_g1_valid28 on the points it marks"},
                 "g2": {"ms": v2_ms, "points_per_s": n / v2_ms * 1e3, "fp_mul_equivalents_per_point": FPMUL_G2_VALID,
-                       "frac": n * FPMUL_G2_VALID * MACS_PER_FPMUL / (v2_ms * 1e-3) / PEAK_MACS, "kernel": "k_g2_valid28"},
+                       "frac": n * FPMUL_G2_VALID * MACS_PER_FPMUL / (v2_ms * 1e-3) / PEAK_MACS,
+                       "kernel": "k_g2_valid_fast (asm steps, two lanes per point) + k_g2_valid28 on the points it marks"},
+                "macs_source": "bench.py FPMUL_G1_VALID / FPMUL_G2_VALID: doubling 2M + 5S, mixed addition 7M + 4S of the inversion-free Jacobian form "
+                               "(Fp2: M = 4, S = 2 Fp mul), G1 two chains of 63 + 5 steps, G2 one, + curve equation / endomorphism / comparison, x 300; "
+                               "recomputable from profiles/r04/workloads_a.json (roofline.config5_*)",
                 "what": "G1Affine::is_valid / G2Affine::is_valid (on-curve + torsion) of the timed batch's points, device-resident; algorithmic count = "
                         "the inversion-free Jacobian form of the reference's tests (its own affine chains cost ~520 inversions per point)"}
+            # config 5 END TO END through the one entry point: raw uncompressed bytes -> decode -> is_valid -> pairing check
+            # (zkp_points_check_batch[_dev]; one pair per check), resident and from page-locked host bytes
+            b1, b2 = eng.encode_points_dev(g1, 1), eng.encode_points_dev(g2, 2)
+            st1 = torch.empty(n, dtype=torch.uint8, device=dev)
+            st2 = torch.empty(n, dtype=torch.uint8, device=dev)
+            pc_ms = wall_ms(lambda: eng.points_check(b1, b2, 1, st1, st2, ok, flag))
+            pc_all_valid = bool((st1 == 0).all().item() and (st2 == 0).all().item()) and not bool(ok.any().item())
+            hb1, hb2 = eng.host_array((n, 96), np.uint8), eng.host_array((n, 192), np.uint8)
+            hb1[:] = b1.cpu().numpy()
+            hb2[:] = b2.cpu().numpy()
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            hs1, hs2, hok, hall = eng.points_check(hb1, hb2, 1)
+            pc_host_ms = (time.perf_counter() - tw) * 1e3
+            fpm5 = FPMUL_G1_VALID + FPMUL_G2_VALID + FPMUL_MILLER + FPMUL_FEXP
+            secondary["config5_points_check"] = {
+                "pairs": n, "resident": {"ms": pc_ms, "pairings_per_s": n / pc_ms * 1e3, "points_per_s": 2 * n / pc_ms * 1e3},
+                "from_page_locked_host_bytes": {"ms": pc_host_ms, "pairings_per_s": n / pc_host_ms * 1e3, "points_per_s": 2 * n / pc_host_ms * 1e3,
+                                                "equal_resident": bool(np.array_equal(hs1, st1.cpu().numpy()) and np.array_equal(hok, ok.cpu().numpy()))},
+                "fp_mul_equivalents_per_pair": fpm5, "frac": n * fpm5 * MACS_PER_FPMUL / (pc_ms * 1e-3) / PEAK_MACS,
+                "all_points_valid_no_pairing_is_one": pc_all_valid,
+                "what": "BASELINE config 5 as ONE call (zkp_points_check_batch_dev): 2^20 uncompressed (G1, G2) byte strings -> Fp::from_bytes range "
+                        "check, G1 / G2 is_valid, fused pairing + Gt::identity() check, status bytes + flags out; decoded points and intermediate "
+                        "status bytes stay in HBM.  PCIe-inclusive figure from page-locked host bytes beside it (never `value`)"}
+            del b1, b2, st1, st2, hb1, hb2
             # host-pointer C ABI (what a Rust / C host binds): H2D + kernels + D2H inside the call, PCIe-inclusive, never `value`
             hp1, hp2 = eng.host_array((n, 12)), eng.host_array((n, 24))
             hgt = eng.host_array((n, 72))
@@ -338,6 +423,9 @@ def main():
                 "peak_clock_ghz": NOMINAL_GHZ, "sustained_clock_ghz": sustained_ghz,
                 "frac_at_sustained_clock": (achieved / (LANES_PER_CLK * sustained_ghz * 1e9)) if sustained_ghz else None,
                 "kernel_ms": kern_ms, "algorithmic_macs_per_pairing": MACS_PER_PAIRING,
+                "algorithmic_macs_source": "SURVEY.md 8(d): 21,869 Fp-mul-equivalents of the reference-shaped schoolbook tower x 300 multiply-adds of a 12-limb CIOS multiply",
+                "executed_macs_per_pairing": executed,
+                "executed_frac_of_peak": ((n * executed["total"]) / (kern_ms * 1e-3) / PEAK_MACS) if executed and executed.get("total") else None,
                 "phases": {
                     "miller_loop": {"ms": ml_ms, "frac": phase(FPMUL_MILLER, ml_ms), "fp_mul_equivalents": FPMUL_MILLER,
                                     "kernels": "k_prep_lines<false> (upstream-shaped lines) + k_coop<30,4> (miller1), Gt-less: Miller value to wire"},
@@ -350,12 +438,12 @@ def main():
                     "k_coop miller": {"ms": mil_ms, "frac": phase(FPMUL_MILLER - FPMUL_LINES, mil_ms), "fp_mul_equivalents": FPMUL_MILLER - FPMUL_LINES,
                                       "what": "Fp12 accumulator: 68 line products + 63 squarings; one 2^16-check launch timed alone, scaled"},
                     "final exponentiation kernels": {"ms": fe_ms, "frac": phase(FPMUL_FEXP, fe_ms), "fp_mul_equivalents": FPMUL_FEXP,
-                                                     "what": "fexp_a, k_batch_inv, the phase C plan (see profiles/r03/*_kernel_stats.txt for its split)"}},
+                                                     "what": "fexp_a, k_batch_inv, the phase C plan (see profiles/r04/*_kernel_stats.txt for its split)"}},
                 "launch": "one pass over the resident batch = phase A per 2^16-check chunk on two overlapped HIP streams (k_prep_lines, k_coop "
                           "miller, k_coop fexp_a), ONE k_batch_inv, then the phase C plan over the whole shard: six step programs "
                           "alternating with five compressed squaring runs (k_ksq) and their decompression (k_kdec_a, k_batch_inv, "
                           "k_kdec_b); kernel_ms is that pass timed with HIP events on the launching stream; the per-kernel split is in "
-                          "profiles/r03/"}
+                          "profiles/r04/"}
         line = {
             "metric": "BLS12-381 pairings/s on 2^20 random (G1,G2) pairs; bit-exact Gt vs ref (CPU oracle: the reference's pairings.rs is empty)",
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -370,6 +458,7 @@ def main():
             "cpu_baseline": cpu,
             "secondary_workloads": secondary,
             "host_api": host_api,
+            "abi_collective": abi_coll,
             "ranks_detail": None if rank_diag is None else {
                 "per_rank": [{"rank": i, "pairs": int(r[3]), "kernel_ms_alone": r[0], "collective_ms_alone": r[1], "step_wall_ms": r[2]}
                              for i, r in enumerate(rank_diag)],
@@ -379,6 +468,8 @@ def main():
                                     "tails weigh more on a smaller grid), so the curve cannot exceed 1.98x / 3.88x / 7.65x"},
         }
         print(json.dumps(line), flush=True)
+    if abi_hung:
+        os._exit(0 if (line is None or line["config"]["gt_sample_bit_exact"] is not False) else 3)   # a stuck RCCL thread must not hold the exit
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -412,7 +412,11 @@ __global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                     }
                 } else {
                     size_t rec;
+#ifdef ZKP_EXP_TRAFFIC4L   // timing-only experiment (wrong results): four checks read one line record
+                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + idx) * A.n_checks + (check & ~3u);
+#else
                     if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + idx) * A.n_checks + check;   // line buffer: this launch's checks only
+#endif
                     else rec = (size_t)(idx + A.st_off) * A.nc + check;
                     const int4* src = (arg == K_LINE ? A.lines : (const int4*)A.state) + rec * 4;
                     int4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
@@ -511,6 +515,18 @@ __device__ __forceinline__ void rec_store(int4* dst, const Fp28& x) {
     dst[2] = make_int4(x.l[8], x.l[9], x.l[10], x.l[11]);
     dst[3] = make_int4(x.l[12], x.l[13], 0, 0);
 }
+#ifdef ZKP_EXP_NT_SNAPSHOT     // experiment: the snapshot stores of k_ksq as non-temporal (streaming) stores
+typedef int zkp_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rec_store_snap(int4* dst, const Fp28& x) {
+    zkp_v4i* d = reinterpret_cast<zkp_v4i*>(dst);
+    __builtin_nontemporal_store((zkp_v4i){x.l[0], x.l[1], x.l[2], x.l[3]}, d);
+    __builtin_nontemporal_store((zkp_v4i){x.l[4], x.l[5], x.l[6], x.l[7]}, d + 1);
+    __builtin_nontemporal_store((zkp_v4i){x.l[8], x.l[9], x.l[10], x.l[11]}, d + 2);
+    __builtin_nontemporal_store((zkp_v4i){x.l[12], x.l[13], 0, 0}, d + 3);
+}
+#else
+#define rec_store_snap rec_store
+#endif
 __device__ __forceinline__ void rec_load(Fp28& x, const int4* src) {
     int4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
     x.l[0] = v0.x; x.l[1] = v0.y; x.l[2] = v0.z; x.l[3] = v0.w; x.l[4] = v1.x; x.l[5] = v1.y; x.l[6] = v1.z; x.l[7] = v1.w;
@@ -699,20 +715,24 @@ __global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t
             int4* const st_ = state + (size_t)(chk_ < n_checks ? chk_ : n_checks - 1) * 4;
             auto rec_ = [&](uint32_t e) -> int4* { return st_ + (size_t)e * nc * 4; };
             const int tu_ = (l_ & 2) ? 1 : 3, tv_ = (l_ & 2) ? 5 : 2;
+#if defined(ZKP_EXP_TRAFFIC4) && (ZKP_EXP_TRAFFIC4 & 1)     // timing-only experiment (wrong results): a quarter of the snapshot records is written
+            if (chk_ < n_checks && a_lane && (chk_ & 3) == 0) {
+#else
             if (chk_ < n_checks && a_lane) {
+#endif
                 Fp28 o;
 #pragma unroll
                 for (int i = 0; i < NL; i++) o.l[i] = xr[i];
-                rec_store(rec_(snap + 2 * (v_mine ? tv_ : tu_)), o);
+                rec_store_snap(rec_(snap + 2 * (v_mine ? tv_ : tu_)), o);
 #pragma unroll
                 for (int i = 0; i < NL; i++) o.l[i] = xi[i];
-                rec_store(rec_(snap + 2 * (v_mine ? tv_ : tu_) + 1), o);
+                rec_store_snap(rec_(snap + 2 * (v_mine ? tv_ : tu_) + 1), o);
 #pragma unroll
                 for (int i = 0; i < NL; i++) o.l[i] = yr[i];
-                rec_store(rec_(snap + 2 * (v_mine ? tu_ : tv_)), o);
+                rec_store_snap(rec_(snap + 2 * (v_mine ? tu_ : tv_)), o);
 #pragma unroll
                 for (int i = 0; i < NL; i++) o.l[i] = yi[i];
-                rec_store(rec_(snap + 2 * (v_mine ? tu_ : tv_) + 1), o);
+                rec_store_snap(rec_(snap + 2 * (v_mine ? tu_ : tv_) + 1), o);
             }
             snap += 12;
         }
@@ -1164,6 +1184,11 @@ __device__ __forceinline__ void dbl_step_cln(G2C& r, int c, S0&& sink_l0, S1&& s
 #define ZKP_PREP_WAVES 2   // measured: 256 VGPRs (2 waves/SIMD) 6.6 ms, 168 -> 9.3 ms, 128 -> 11.4 ms per 2^17 pairs (spill traffic)
 #endif
 // CLN: homogeneous projective steps with freely scaled lines (fused pairing paths); otherwise the upstream-shaped Alg. 26 / 27.
+#ifdef ZKP_EXP_TRAFFIC4L
+#define ZKP_EXP_LINE_KEEP(check) (((check) & 3u) == 0)     // timing-only experiment: a quarter of the line records is written
+#else
+#define ZKP_EXP_LINE_KEEP(check) true
+#endif
 template <bool CLN>
 __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
                                                        uint32_t n_pairs, uint32_t k, uint32_t k_in, uint32_t j0, uint32_t nc, int4* lines) {
@@ -1252,7 +1277,7 @@ __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_
 #define ZKP_PREP_STEP_ASM(BLOCK)                                                                                                          \
         do {                                                                                                                              \
             constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};                                                                                  \
-            const unsigned long long smask = __ballot(live_lane && !dead);                                                                \
+            const unsigned long long smask = __ballot(live_lane && !dead && ZKP_EXP_LINE_KEEP(check));                                    \
             const uint64_t sb_ = (uint64_t)(uintptr_t)lines + (uint64_t)step * k * 6 * nc * 64;   /* wave-uniform: made scalar by hand */ \
             const char* const sbase = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb_ >> 32)) << 32) |  \
                                                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb_));                  \
@@ -1901,10 +1926,15 @@ __global__ void __launch_bounds__(64, 2) k_kdec_a(int4* state, uint32_t n_checks
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
     const int c = (int)(tid & 1);
     uint32_t e = tid >> 1;
-    const bool live = e < n_checks * count;
+    bool live = e < n_checks * count;
     if (!live) e = n_checks * count - 1;
     const uint32_t sn = e / n_checks, check = e - sn * n_checks;
+#if defined(ZKP_EXP_TRAFFIC4) && (ZKP_EXP_TRAFFIC4 & 2)
+    int4* const st = state + (size_t)(check & ~3u) * 4;
+    if (check & 3) live = false;
+#else
     int4* const st = state + (size_t)check * 4;
+#endif
     const uint32_t base = elem_snap + 12 * sn;
     auto rec = [&](uint32_t el) -> int4* { return st + (size_t)el * nc * 4; };
     F2 f{c};
@@ -1943,10 +1973,15 @@ __global__ void __launch_bounds__(64, 2) k_kdec_b(int4* state, uint32_t n_checks
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
     const int c = (int)(tid & 1);
     uint32_t e = tid >> 1;
-    const bool live = e < n_checks * count;
+    bool live = e < n_checks * count;
     if (!live) e = n_checks * count - 1;
     const uint32_t sn = e / n_checks, check = e - sn * n_checks;
+#if defined(ZKP_EXP_TRAFFIC4) && (ZKP_EXP_TRAFFIC4 & 2)
+    int4* const st = state + (size_t)(check & ~3u) * 4;
+    if (check & 3) live = false;
+#else
     int4* const st = state + (size_t)check * 4;
+#endif
     const uint32_t base = elem_snap + 12 * sn;
     auto rec = [&](uint32_t el) -> int4* { return st + (size_t)el * nc * 4; };
     F2 f{c};
@@ -2316,10 +2351,10 @@ static hipError_t miller_on_pipe(CoopDev* d, CoopPipe* pp, const uint64_t* g1, c
 // stream `s` is forked into the pipeline streams (they wait for everything already queued on `s`) and
 // joined again at the end, so from the caller's point of view the call is ordered on `s`.
 template <class Body>
-static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lines, bool need_state, hipStream_t s, Body body) {
+static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lines, bool need_state, hipStream_t s, Body body, size_t chunk_override = 0) {
     if (!n_total) return hipSuccess;
     hipError_t e;
-    size_t chunk = d->chunk;
+    size_t chunk = chunk_override ? chunk_override : d->chunk;
     if (need_lines && k > 4) {   // keep the line buffer at the size four pairs per check need
         chunk = chunk * 4 / (k < MAX_GROUP ? k : MAX_GROUP);
         if (chunk < 320) chunk = 320;
@@ -2433,7 +2468,17 @@ static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_line
         if ((e = run_inv(d, s, d->big_state, (uint32_t)ns, (uint32_t)ns, ZKP_COOP_ST_N, ZKP_COOP_ST_NINV, 1)) != hipSuccess) return e;
         // phase C needs no line buffer: one pass over a large super-chunk has no per-chunk tails (-1 % at 2^20
         // checks); small ones do better per chunk on the two pipelines (-1 % at 2^17)
-        if (d->c_single && ns > d->c_single_min) {
+        // experiment knob (round 4): phase C in c_split parts on the pipelines' streams, so that one part's latency-bound
+        // islands (k_batch_inv, k_kdec_a / _b) can run beside another part's step programs and squaring runs
+        static const int c_split = getenv("ZKP_COOP_C_SPLIT") ? atoi(getenv("ZKP_COOP_C_SPLIT")) : 0;
+        if (c_split > 1 && ns > d->c_single_min) {
+            const size_t part = ((ns + c_split - 1) / c_split + 15) / 16 * 16;
+            e = for_chunks(d, ns, 1, false, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
+                CoopPipe v = *pp;
+                v.state = d->big_state + 4 * base;
+                return run_fexp_c(d, &v, n, (uint32_t)ns, out ? out + 72 * (sb + base) : nullptr, ok ? ok + sb + base : nullptr, all_ok);
+            }, part);
+        } else if (d->c_single && ns > d->c_single_min) {
             CoopPipe v = d->pipe[0];
             v.state = d->big_state;
             v.stream = s;
