@@ -515,18 +515,6 @@ __device__ __forceinline__ void rec_store(int4* dst, const Fp28& x) {
     dst[2] = make_int4(x.l[8], x.l[9], x.l[10], x.l[11]);
     dst[3] = make_int4(x.l[12], x.l[13], 0, 0);
 }
-#ifdef ZKP_EXP_NT_SNAPSHOT     // experiment: the snapshot stores of k_ksq as non-temporal (streaming) stores
-typedef int zkp_v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void rec_store_snap(int4* dst, const Fp28& x) {
-    zkp_v4i* d = reinterpret_cast<zkp_v4i*>(dst);
-    __builtin_nontemporal_store((zkp_v4i){x.l[0], x.l[1], x.l[2], x.l[3]}, d);
-    __builtin_nontemporal_store((zkp_v4i){x.l[4], x.l[5], x.l[6], x.l[7]}, d + 1);
-    __builtin_nontemporal_store((zkp_v4i){x.l[8], x.l[9], x.l[10], x.l[11]}, d + 2);
-    __builtin_nontemporal_store((zkp_v4i){x.l[12], x.l[13], 0, 0}, d + 3);
-}
-#else
-#define rec_store_snap rec_store
-#endif
 __device__ __forceinline__ void rec_load(Fp28& x, const int4* src) {
     int4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
     x.l[0] = v0.x; x.l[1] = v0.y; x.l[2] = v0.z; x.l[3] = v0.w; x.l[4] = v1.x; x.l[5] = v1.y; x.l[6] = v1.z; x.l[7] = v1.w;
@@ -723,16 +711,16 @@ __global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t
                 Fp28 o;
 #pragma unroll
                 for (int i = 0; i < NL; i++) o.l[i] = xr[i];
-                rec_store_snap(rec_(snap + 2 * (v_mine ? tv_ : tu_)), o);
+                rec_store(rec_(snap + 2 * (v_mine ? tv_ : tu_)), o);
 #pragma unroll
                 for (int i = 0; i < NL; i++) o.l[i] = xi[i];
-                rec_store_snap(rec_(snap + 2 * (v_mine ? tv_ : tu_) + 1), o);
+                rec_store(rec_(snap + 2 * (v_mine ? tv_ : tu_) + 1), o);
 #pragma unroll
                 for (int i = 0; i < NL; i++) o.l[i] = yr[i];
-                rec_store_snap(rec_(snap + 2 * (v_mine ? tu_ : tv_)), o);
+                rec_store(rec_(snap + 2 * (v_mine ? tu_ : tv_)), o);
 #pragma unroll
                 for (int i = 0; i < NL; i++) o.l[i] = yi[i];
-                rec_store_snap(rec_(snap + 2 * (v_mine ? tu_ : tv_) + 1), o);
+                rec_store(rec_(snap + 2 * (v_mine ? tu_ : tv_) + 1), o);
             }
             snap += 12;
         }
