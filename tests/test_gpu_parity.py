@@ -344,6 +344,50 @@ def test_validity_of_small_order_and_cofactor_points(keng, model_vectors):
     assert np.array_equal(keng.g1_is_valid(h1), exp1) and np.array_equal(keng.g2_is_valid(h2), exp2)
 
 
+def test_validity_kernel_variants_agree(eng, model_vectors):
+    """the asm subgroup checks (default: G1 and G2 at three waves per SIMD) against their own alternatives in fresh processes -
+    ZKP_G2_VALID_WAVES=2 (the two-wave G2 kernel) and ZKP_VALID_GENERIC=1 (the compiled kernels of round 3 alone) - on a batch that
+    holds every class: subgroup points, curve points outside the subgroup, small-order points (the asm chain meets P + P / P - P /
+    infinity there and hands the point to the generic kernel), off-curve points, infinities"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from zkvm_pairings_amd import configs, synthetic
+    n = 6000
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        data = {}
+        for which in (1, 2):
+            raw, cls = configs.raw_points(eng, n, which, 4242 + which)
+            pts, inf, st = eng.decode_points(raw, which)
+            # cofactor-torsion points (and the order-3 points (0, +-2) of E(Fp)): the exceptional cases of the group law
+            extra = [o.ints_to_arr([0, 2]), o.ints_to_arr([0, m.P - 2])] if which == 1 else []
+            for v in model_vectors["groups"]["g1_validity" if which == 1 else "g2_validity"]:
+                if v["status"] == 2:
+                    tors, tinf = (o.g1_mul if which == 1 else o.g2_mul)(A(v["p"]), m.R_ORDER)
+                    if not tinf:
+                        extra.append(tors)
+            for j, e in enumerate(extra[:16]):
+                pts[j], inf[j] = e, 0
+            np.save(os.path.join(td, "p%d.npy" % which), pts)
+            np.save(os.path.join(td, "i%d.npy" % which), inf)
+            data[which] = (eng.g1_is_valid if which == 1 else eng.g2_is_valid)(pts, inf)
+        code = (
+            "import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "import zkvm_pairings_amd as z\n"
+            "e = z.PairingEngine(0)\n"
+            "for w in (1, 2):\n"
+            "    p, i = np.load(%r + '/p%%d.npy' %% w), np.load(%r + '/i%%d.npy' %% w)\n"
+            "    np.save(%r + '/s%%d.npy' %% w, (e.g1_is_valid if w == 1 else e.g2_is_valid)(p, i))\n" % (root, td, td, td))
+        for env in ({"ZKP_G2_VALID_WAVES": "2"}, {"ZKP_VALID_GENERIC": "1"}):
+            out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, out.stderr[-1500:]
+            for which in (1, 2):
+                assert np.array_equal(np.load(os.path.join(td, "s%d.npy" % which)), data[which]), (env, which)
+        assert set(np.unique(data[1])) == {0, 1, 2} and set(np.unique(data[2])) == {0, 1, 2}
+
+
 def test_pairing_golden(keng, model_vectors):
     from zkvm_pairings_amd import synthetic
     pr = model_vectors["pairing"]

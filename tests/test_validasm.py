@@ -183,6 +183,84 @@ def test_g2_doubling_and_addition_chain_equals_the_group_law():
             assert _jac_to_affine2(*got) == acc[k], (step, kind, k)
 
 
+def _lds_get(emu, slot, lane):
+    return [asmemu.s32(emu.lds[(slot * 4 + i // 4) * 1024 + 16 * lane + 4 * (i % 4)]) for i in range(NL)]
+
+
+def test_g2_three_wave_steps_equal_the_group_law():
+    """the five-block variants (three waves per SIMD): Y in registers, X and Z in LDS slots, the affine point from the scratch
+    buffer - same formulas, same bounds, same chain as the two-wave blocks"""
+    rng = random.Random(53)
+    dbl, madd = validasm.g2_dbl3(), validasm.g2_madd3()
+    assert dbl.vend <= 168 and madd.vend <= 168
+    pairs = 2
+    lanes = 2 * pairs
+    pts = [m.g2_mul(m.G2_GEN, rng.randrange(2, 1 << 64)) for _ in range(pairs)]
+    sub = _subst()
+    sub.update({"qstride": "s120", "qlo": "s121", "qhi": "s122", "qoff": "v1"})
+    emu = asmemu.Emu(lanes=lanes, subst=sub)
+    qbase, qstride = 0x500000, 16 * lanes
+    emu.s[120], emu.s[121], emu.s[122] = qstride, qbase, 0
+    emu.v[1] = [16 * lane for lane in range(lanes)]
+    Y = dbl.R[1]
+    for k, (x, y) in enumerate(pts):
+        for c in range(2):
+            lane = 2 * k + c
+            _put(emu, Y, lane, cg.mont(y[c]))
+            _lds_put(emu, validasm.LX, lane, cg.mont(x[c]))
+            _lds_put(emu, validasm.LZ, lane, cg.mont(1 if c == 0 else 0))
+            for v, val in ((0, x[c]), (1, y[c])):
+                l = cg.mont(val)
+                for i in range(16):
+                    emu.mem[qbase + ((v * 4 + i // 4) * lanes + lane) * 16 + 4 * (i % 4)] = (l[i] if i < NL else 0) & asmemu.M32
+    acc = list(pts)
+
+    def state(k):
+        return (tuple(cg.from_mont(_lds_get(emu, validasm.LX, 2 * k + c)) for c in range(2)),
+                tuple(cg.from_mont(_get(emu, Y, 2 * k + c)) for c in range(2)),
+                tuple(cg.from_mont(_lds_get(emu, validasm.LZ, 2 * k + c)) for c in range(2)))
+
+    for step, kind in enumerate("ddaddadda"):
+        before = [state(k) for k in range(pairs)]
+        emu.run(dbl.lines if kind == "d" else madd.lines)
+        assert emu.exec == (1 << lanes) - 1
+        for k in range(pairs):
+            for c in range(2):
+                _check_reduced(_lds_get(emu, validasm.LX, 2 * k + c), *((-2.2, 2.2) if kind == "d" else (-0.52, 0.52)))
+                _check_reduced(_get(emu, Y, 2 * k + c))
+                _check_reduced(_lds_get(emu, validasm.LZ, 2 * k + c))
+            x1, y1, z1 = before[k]
+            if kind == "d":
+                A, B = m.f2_sqr(x1), m.f2_sqr(y1)
+                S, M = _f2k(m.f2_mul(x1, B), 4), _f2k(A, 3)
+                nx = m.f2_sub(m.f2_sqr(M), _f2k(S, 2))
+                want = (nx, m.f2_sub(m.f2_mul(M, m.f2_sub(S, nx)), _f2k(m.f2_sqr(B), 8)), _f2k(m.f2_mul(y1, z1), 2))
+                acc[k] = m.g2_add(acc[k], acc[k])
+            else:
+                qx, qy = pts[k]
+                zz = m.f2_sqr(z1)
+                H, r = m.f2_sub(m.f2_mul(qx, zz), x1), m.f2_sub(m.f2_mul(qy, m.f2_mul(z1, zz)), y1)
+                HH = m.f2_sqr(H)
+                HHH, V = m.f2_mul(H, HH), m.f2_mul(x1, HH)
+                nx = m.f2_sub(m.f2_sub(m.f2_sqr(r), HHH), _f2k(V, 2))
+                want = (nx, m.f2_sub(m.f2_mul(r, m.f2_sub(V, nx)), m.f2_mul(y1, HHH)), m.f2_mul(z1, H))
+                acc[k] = m.g2_add(acc[k], pts[k])
+            got = state(k)
+            assert got == want, (step, kind, k)
+            assert _jac_to_affine2(*got) == acc[k], (step, kind, k)
+    # P + P through the addition: Z' = 0 and it stays 0
+    for k, (x, y) in enumerate(pts):
+        for c in range(2):
+            lane = 2 * k + c
+            _put(emu, Y, lane, cg.mont(y[c]))
+            _lds_put(emu, validasm.LX, lane, cg.mont(x[c]))
+            _lds_put(emu, validasm.LZ, lane, cg.mont(1 if c == 0 else 0))
+    for blk in (madd, dbl, madd):
+        emu.run(blk.lines)
+        for k in range(pairs):
+            assert state(k)[2] == (0, 0)
+
+
 def test_g2_exceptional_cases_send_z_to_zero():
     dbl, madd = validasm.g2_dbl(), validasm.g2_madd()
     p2 = m.g2_mul(m.G2_GEN, 5)

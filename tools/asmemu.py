@@ -247,6 +247,9 @@ class Emu:
     def op_s_mul_i32(self, a, m):
         self._sw(a[0], s32(self._sr(a[1])) * s32(self._sr(a[2])))
 
+    def op_s_mul_hi_u32(self, a, m):
+        self._sw(a[0], (self._sr(a[1]) * self._sr(a[2])) >> 32)
+
     def op_s_cmp_ge_u32(self, a, m):
         self.scc = int(self._sr(a[0]) >= self._sr(a[1]))
 
@@ -284,6 +287,9 @@ class Emu:
                 val = self.rd(a[1], lane, 4)
                 for k in range(4):
                     self.mem[addr + 4 * k] = (val >> (32 * k)) & M32
+
+    def op_global_load_dwordx4(self, a, m):
+        self._gload(a, m, 4)
 
     def op_global_load_dwordx3(self, a, m):
         self._gload(a, m, 3)
@@ -340,6 +346,11 @@ class Emu:
             self.vcc = 0
         if (self.rd(a[1], l) & M32) != (self.rd(a[2], l) & M32):
             self.vcc |= 1 << l
+
+    def op_v_swap_b32(self, a, l, sl):
+        x, y = self.rd(a[0], l), self.rd(a[1], l)
+        self.wr(a[0], l, y)
+        self.wr(a[1], l, x)
 
     def op_v_mov_b32(self, a, l, sl):
         self.wr(a[0], l, self.rd(a[1], sl))

@@ -58,8 +58,9 @@ class FpStep:
             self.MID[k] = v; v += 2
         self.vend = v
         assert self.vend <= 168, self.vend          # three waves per SIMD
-        # temporaries that live in the accumulator registers while no product is in flight
-        self.vq, self.vt, self.vlds = self.ACC[0], self.ACC[0] + 1, self.ACC[1]
+        # temporaries: the renormalisation's live in accumulator registers (never used while an accumulation is in flight); the LDS
+        # address lives in the difference block, which is free BETWEEN the products of a lazy accumulation too
+        self.vq, self.vt, self.vlds = self.ACC[0], self.ACC[0] + 1, self.D + 13
         self.vc = self.D                       # carries of the one-pass normalisation
         s = 36
         self.sb = s
@@ -266,6 +267,188 @@ def g2_madd(vb=6):
     return g
 
 
+# ---------------------------------------------------------------------------------------------------------------- G2 at three waves per SIMD
+class Fp2Step3(FpStep):
+    """Fp2 on a lane pair in the register budget of three waves per SIMD: five 14-register value blocks R0..R4 + the Karatsuba product
+    set (162 VGPRs).  An Fp2 product needs four operand blocks (a, b and the pair partner's a', b'), so between steps only Y stays
+    in registers (R1): X lives in LDS slot 0, Z in slot 1, slot 2 is the addition's parking place (12 KB per wavefront, twelve
+    wavefronts per CU); the affine point of the additions comes from a scratch buffer in global memory (five loads per chain)."""
+
+    def __init__(self, vb=6):
+        super().__init__(vb)
+        self.R = [self.X, self.Y, self.Z, self.V0, self.V1]
+        s = self.send
+        self.sEX = s; s += 2
+        self.sM0 = s; s += 2
+        self.sM1 = s; s += 2
+        self.sQ = s; s += 2                   # running pointer of the scratch loads
+        self.send = s
+
+    def prologue(self):
+        super().prologue()
+        self.e("s_mov_b64 s[%d:%d], exec" % (self.sEX, self.sEX + 1))
+        for (sr, m) in ((self.sM0, 0x55555555), (self.sM1, 0xaaaaaaaa)):
+            self.e("s_mov_b32 s%d, 0x%x" % (sr, m))
+            self.e("s_mov_b32 s%d, 0x%x" % (sr + 1, m))
+            self.e("s_and_b64 s[%d:%d], s[%d:%d], s[%d:%d]" % (sr, sr + 1, sr, sr + 1, self.sEX, self.sEX + 1))
+
+    def all_lanes(self):
+        self.e("s_mov_b64 exec, s[%d:%d]" % (self.sEX, self.sEX + 1))
+
+    def lanes(self, c):
+        m = self.sM1 if c else self.sM0
+        self.e("s_mov_b64 exec, s[%d:%d]" % (m, m + 1))
+
+    def swap(self, d, a):
+        self.e("s_nop 1")
+        for i in range(NL):
+            self.e("v_mov_b32_dpp v%d, v%d %s" % (d + i, a + i, prepasm.QP))
+
+    def forms(self, a, x, y):
+        """operand forms of the squaring of a on this lane: c = 0: x = a' + a, y = a - a';  c = 1: x = 2 a', y = a"""
+        self.swap(y, a)
+        self.lanes(0)
+        self.add(x, y, a)
+        self.sub(y, a, y)
+        self.lanes(1)
+        self.add(x, y, y)
+        self.mov(y, a)
+        self.all_lanes()
+
+    def mul_acc(self, a, b, ra, rb, first, la, lb, restore):
+        """the lazy accumulation (+)= coefficient c of a b: c = 0: a b - a' b', c = 1: a b' + a' b.  ra, rb: blocks for the partner's
+        values.  On c = 1 lanes b and b' change places for the products (v_swap); restore puts b back."""
+        self.swap(ra, a)
+        self.swap(rb, b)
+        self.lanes(1)
+        for i in range(NL):
+            self.e("v_swap_b32 v%d, v%d" % (b + i, rb + i))
+        self.lanes(0)
+        self.neg(ra, ra)
+        self.all_lanes()
+        self.prod(a, b, first, la, lb)
+        self.prod(ra, rb, False, la, lb)
+        if restore:
+            self.lanes(1)
+            for i in range(NL):
+                self.e("v_swap_b32 v%d, v%d" % (b + i, rb + i))
+            self.all_lanes()
+
+    def gload(self, dst, v):
+        """value v (0: qx, 1: qy) of this lane from the scratch buffer: quad q at qbase + ((v * 4 + q) * lanes + lane) * 16"""
+        self.e("s_mul_i32 s%d, %%[qstride], %d" % (self.sQ, 4 * v))
+        self.e("s_mul_hi_u32 s%d, %%[qstride], %d" % (self.sQ + 1, 4 * v))
+        self.e("s_add_u32 s%d, s%d, %%[qlo]" % (self.sQ, self.sQ))
+        self.e("s_addc_u32 s%d, s%d, %%[qhi]" % (self.sQ + 1, self.sQ + 1))
+        for q in range(4):
+            if q < 3:
+                self.e("global_load_dwordx4 v[%d:%d], %%[qoff], s[%d:%d]" % (dst + 4 * q, dst + 4 * q + 3, self.sQ, self.sQ + 1))
+                self.e("s_add_u32 s%d, s%d, %%[qstride]" % (self.sQ, self.sQ))
+                self.e("s_addc_u32 s%d, s%d, 0" % (self.sQ + 1, self.sQ + 1))
+            else:
+                self.e("global_load_dwordx2 v[%d:%d], %%[qoff], s[%d:%d]" % (dst + 12, dst + 13, self.sQ, self.sQ + 1))
+        self.e("s_waitcnt vmcnt(0)")
+
+
+LX, LZ, LT = 0, 1, 2        # LDS slots of the three-wave G2 kernel: X, Z, the addition's parking place
+
+
+def g2_dbl3(vb=6):
+    """g2_dbl's doubling in five register blocks; in / out: Y in R1, X in LDS slot LX, Z in slot LZ"""
+    g = Fp2Step3(vb)
+    R0, R1, R2, R3, R4 = g.R
+    D = g.D
+    g.prologue()
+    g.lds_read(R2, LZ)
+    g.shl(R3, R1, 1)
+    g.mul_acc(R3, R2, R4, R0, True, 2, 1, False)
+    tail(g, R2)                           # Z' = (2Y) Z
+    g.lds_write(R2, LZ)
+    g.forms(R1, R4, R3)
+    g.prod(R4, R3, True, 2, 2)
+    tail(g, R0)                           # B = Y^2
+    g.lds_read(R1, LX)
+    g.forms(R1, R4, R3)
+    g.times3(R3, R3)
+    g.prod(R4, R3, True, 2, 6)
+    tail(g, R2)                           # M = 3 X^2
+    g.shl(R1, R1, 2)
+    g.mul_acc(R1, R0, R3, R4, True, 4, 1, True)
+    tail(g, R1)                           # S = (4X) B   (B restored)
+    g.forms(R2, R4, R3)
+    g.prod(R4, R3, True, 2, 2)
+    tail(g, R3)                           # M^2
+    g.neg(D, R1)
+    g.shl_add(R3, D, 1, R3)               # X' = M^2 - 2S
+    g.norm(R3)
+    g.sub(R1, R1, R3)                     # S - X'
+    g.lds_write(R3, LX)
+    g.mul_acc(R2, R1, R3, R4, True, 1, 2, False)
+    g.forms(R0, R4, R3)
+    g.norm(R4)
+    g.shl(R4, R4, 2)
+    g.neg(R4, R4)
+    g.shl(R3, R3, 1)
+    g.prod(R4, R3, False, 4, 4)
+    tail(g, R1)                           # Y' = M (S - X') - 8 B^2
+    return g
+
+
+def g2_madd3(vb=6):
+    """g2_madd's mixed addition in five register blocks; the affine point comes from the scratch buffer"""
+    g = Fp2Step3(vb)
+    R0, R1, R2, R3, R4 = g.R
+    D = g.D
+    g.prologue()
+    g.lds_write(R1, LT)                   # Y parked
+    g.lds_read(R2, LZ)
+    g.forms(R2, R4, R3)
+    g.prod(R4, R3, True, 2, 2)
+    tail(g, R0)                           # ZZ
+    g.mul_acc(R2, R0, R3, R4, True, 1, 1, True)
+    tail(g, R3)                           # ZZZ  (ZZ restored)
+    g.gload(R1, 0)
+    g.mul_acc(R1, R0, R2, R4, True, 1, 1, False)
+    tail(g, R0)                           # U2 = qx ZZ
+    g.lds_read(R1, LX)
+    g.sub(R0, R0, R1)                     # H
+    g.gload(R1, 1)
+    g.mul_acc(R1, R3, R2, R4, True, 1, 1, False)
+    tail(g, R3)                           # S2 = qy ZZZ
+    g.lds_read(R1, LT)
+    g.sub(R3, R3, R1)                     # r
+    g.lds_read(R1, LZ)
+    g.mul_acc(R1, R0, R2, R4, True, 1, 2, True)
+    tail(g, R1)                           # Z' = Z H   (H restored)
+    g.lds_write(R1, LZ)
+    g.forms(R0, R2, R1)
+    g.prod(R2, R1, True, 4, 4)
+    tail(g, R1)                           # HH
+    g.mul_acc(R0, R1, R2, R4, True, 2, 1, True)
+    tail(g, R0)                           # HHH  (HH restored)
+    g.lds_read(R2, LX)                    # X
+    g.lds_write(R0, LX)                   # HHH parked in X's slot
+    g.mul_acc(R2, R1, R4, R0, True, 1, 1, False)
+    tail(g, R1)                           # V = X HH
+    g.forms(R3, R2, R0)
+    g.prod(R2, R0, True, 4, 4)
+    tail(g, R2)                           # r^2
+    g.lds_read(R0, LX)                    # HHH
+    g.sub(R2, R2, R0)
+    g.neg(D, R1)
+    g.shl_add(R2, D, 1, R2)               # X' = r^2 - HHH - 2V
+    g.norm(R2)
+    g.vred(R2)
+    g.sub(R1, R1, R2)                     # V - X'
+    g.lds_write(R2, LX)
+    g.mul_acc(R3, R1, R2, R4, True, 2, 2, False)
+    g.lds_read(R3, LT)                    # Y
+    g.neg(R3, R3)
+    g.mul_acc(R3, R0, R2, R4, False, 1, 1, False)
+    tail(g, R1)                           # Y' = r (V - X') - Y HHH
+    return g
+
+
 def _emit(f, name, g, comment):
     n = sum(1 for l in g.lines if not l.endswith(":"))
     f.write("// %s: %d instructions; VGPRs v%d..v%d, SGPRs s%d..s%d.\n" % (comment, n, g.vb, g.vend - 1, g.sb, g.send - 1))
@@ -295,6 +478,15 @@ def write_inc(path, vb=6):
             f.write("#define ZKP_%s_STEP_CLOBBERS " % nm + ", ".join('"v%d"' % v for v in range(first, g.vend)) + ", "
                     + ", ".join('"s%d"' % s for s in range(g.sb, g.send)) + ', "vcc", "scc", "memory"\n')
         f.write("#define ZKP_G1_STEP_VGPR_END %d\n#define ZKP_G2_STEP_VGPR_END %d\n" % (g1d.vend, g2d.vend))
+        # the three-wave G2 variant: Y in registers (in / out), X and Z in LDS slots 0 and 1, slot 2 parks; the affine point comes from
+        # a scratch buffer: [qlo]:[qhi] its base (two SGPR inputs), [qstride] the bytes of one limb-quad plane, [qoff] the lane's offset
+        g3d, g3a = g2_dbl3(vb), g2_madd3(vb)
+        counts += [_emit(f, "ZKP_G2W3_DBL_ASM", g3d, "G2 doubling, three waves per SIMD (Y in registers; X, Z in LDS slots 0, 1)"),
+                   _emit(f, "ZKP_G2W3_MADD_ASM", g3a, "G2 mixed addition, three waves per SIMD (affine point from the scratch buffer; LDS slot 2 parks)")]
+        ybase = g3d.R[1]
+        f.write("#define ZKP_G2W3_STEP_IO(y) " + ", ".join('"+{v%d}"((y)[%d])' % (ybase + i, i) for i in range(NL)) + "\n")
+        f.write("#define ZKP_G2W3_STEP_CLOBBERS " + ", ".join('"v%d"' % v for v in range(g3d.vb, g3d.vend) if not ybase <= v < ybase + NL) + ", "
+                + ", ".join('"s%d"' % s for s in range(g3d.sb, g3d.send)) + ', "vcc", "scc", "memory"\n')
     return counts, (g1d, g1a, g2d, g2a)
 
 
@@ -302,5 +494,5 @@ if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "zkvm_pairings_amd", "csrc", "zkp_valid_steps.inc")
     counts, gs = write_inc(path)
-    print("wrote %s: G1 dbl %d, madd %d (v%d..v%d); G2 dbl %d, madd %d (v%d..v%d) instructions"
-          % (path, counts[0], counts[1], gs[0].vb, gs[0].vend - 1, counts[2], counts[3], gs[2].vb, gs[2].vend - 1))
+    print("wrote %s: G1 dbl %d, madd %d (v%d..v%d); G2 dbl %d, madd %d (v%d..v%d); G2 at three waves dbl %d, madd %d instructions"
+          % (path, counts[0], counts[1], gs[0].vb, gs[0].vend - 1, counts[2], counts[3], gs[2].vb, gs[2].vend - 1, counts[4], counts[5]))

@@ -1629,6 +1629,96 @@ __global__ void __launch_bounds__(64, 2) k_g2_valid_fast(const uint64_t* g2, con
     }
     if (live && c == 0) status[i] = is_inf ? 0 : (on ? st : 1);
 }
+
+// the same check at THREE waves per SIMD (tools/validasm.py g2_dbl3 / g2_madd3): five register blocks + the Karatsuba product set =
+// 168 VGPRs.  Between steps only Y is in registers; X and Z live in LDS slots 0 and 1 (slot 2 parks a value inside the addition), the
+// affine point's limbs - needed by the five additions - in `qs`: quad q of value v (0: x, 1: y) of global lane t at
+// qs[(v * 4 + q) * lanes + t].
+__global__ void __launch_bounds__(64, 3) k_g2_valid_fast3(const uint64_t* g2, const uint8_t* inf, uint32_t n, uint8_t* status, int4* qs) {
+    extern __shared__ int4 park[];
+    const int lane = threadIdx.x;
+    const uint32_t tid = blockIdx.x * 64 + lane;
+    const uint32_t lanes = gridDim.x * 64;
+    const int c = (int)(tid & 1);
+    uint32_t i = tid >> 1;
+    if (i >= n) i = n - 1;
+    const bool is_inf = inf && inf[i];
+    bool on;
+    int32_t Y[NL];
+    {
+        F2 f{c};
+        Fp28 x, y;
+        fp28_from_wire(x, g2 + 24 * (size_t)i + 6 * c);
+        fp28_from_wire(y, g2 + 24 * (size_t)i + 12 + 6 * c);
+        Fp28 lhs = f.sqr(y);
+        Fp28 rhs = c_add(f.mul(f.sqr(x), x), f_const(K28_B));
+        on = f.is_zero(c_sub(lhs, rhs));
+        valid_park(park, lane, 0, x);
+        valid_park(park, lane, 1, f.one());
+        const Fp28* v[2] = {&x, &y};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            qs[(size_t)(k * 4 + 0) * lanes + tid] = make_int4(v[k]->l[0], v[k]->l[1], v[k]->l[2], v[k]->l[3]);
+            qs[(size_t)(k * 4 + 1) * lanes + tid] = make_int4(v[k]->l[4], v[k]->l[5], v[k]->l[6], v[k]->l[7]);
+            qs[(size_t)(k * 4 + 2) * lanes + tid] = make_int4(v[k]->l[8], v[k]->l[9], v[k]->l[10], v[k]->l[11]);
+            qs[(size_t)(k * 4 + 3) * lanes + tid] = make_int4(v[k]->l[12], v[k]->l[13], 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) Y[k] = y.l[k];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the lane reads its own scratch records back inside the additions
+    if (!__any(on && !is_inf)) {
+        if (tid < 2 * n && c == 0) status[i] = is_inf ? 0 : 1;
+        return;
+    }
+    int flags = (on ? 1 : 0) | (is_inf ? 2 : 0);
+    const uint32_t qoff = tid * 16u, qstride = lanes * 16u;
+    const uint32_t qlo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)qs);
+    const uint32_t qhi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)qs >> 32));
+#define ZKP_G2W3_STEP(BLOCK)                                                                                                             \
+    do {                                                                                                                                 \
+        constexpr uint32_t PL[NL] = {ZKP28_P_LIMBS};                                                                                     \
+        asm volatile(BLOCK                                                                                                               \
+                     : ZKP_G2W3_STEP_IO(Y)                                                                                               \
+                     : [qoff] "v"(qoff), [qstride] "s"(qstride), [qlo] "s"(qlo), [qhi] "s"(qhi),                                         \
+                       [p0] "s"(PL[0]), [p1] "s"(PL[1]), [p2] "s"(PL[2]), [p3] "s"(PL[3]), [p4] "s"(PL[4]), [p5] "s"(PL[5]),            \
+                       [p6] "s"(PL[6]), [p7] "s"(PL[7]), [p8] "s"(PL[8]), [p9] "s"(PL[9]), [p10] "s"(PL[10]), [p11] "s"(PL[11]),        \
+                       [p12] "s"(PL[12]), [p13] "s"(PL[13]), [pinv] "s"(ZKP28_PINV)                                                      \
+                     : ZKP_G2W3_STEP_CLOBBERS);                                                                                          \
+    } while (0)
+    const uint64_t xs = 0xd201000000010000ULL;
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+        ZKP_G2W3_STEP(ZKP_G2W3_DBL_ASM);
+        if ((xs >> b) & 1) ZKP_G2W3_STEP(ZKP_G2W3_MADD_ASM);
+    }
+    int l_ = threadIdx.x;
+    asm volatile("" : "+v"(l_), "+v"(flags));
+    const uint32_t t_ = blockIdx.x * 64 + (uint32_t)l_;
+    const int c_ = (int)(t_ & 1);
+    uint32_t i_ = t_ >> 1;
+    const bool live_ = i_ < n;
+    if (!live_) i_ = n - 1;
+    F2 f{c_};
+    JacP p;
+    p.x = valid_unpark(park, l_, 0);
+    p.z = valid_unpark(park, l_, 1);
+#pragma unroll
+    for (int k = 0; k < NL; k++) p.y.l[k] = Y[k];
+    uint8_t st;
+    if (f.is_zero(p.z)) {
+        st = VALID_REDO;
+    } else {
+        Fp28 x, y;
+        fp28_from_wire(x, g2 + 24 * (size_t)i_ + 6 * c_);
+        fp28_from_wire(y, g2 + 24 * (size_t)i_ + 12 + 6 * c_);
+        Fp28 cx = c_ ? c_neg(x) : x, cy = c_ ? c_neg(y) : y;
+        Fp28 kx = f_const(c_ ? K28_PSI_X_1 : K28_PSI_X_0), ky = f_const(c_ ? K28_PSI_Y_1 : K28_PSI_Y_0);
+        Fp28 qx = f.mul(cx, kx), qy = f.mul(cy, ky);
+        st = jac_eq_affine(f, p, qx, c_neg(qy)) ? 0 : 2;
+    }
+    if (live_ && c_ == 0) status[i_] = (flags & 2) ? 0 : ((flags & 1) ? st : 1);
+}
 #endif
 
 // a^(p-2) (Fermat; reference src/fp.rs:307-319); a == 0 gives 0.  Kept as the cross-check of f_inv (ZKP_INV_FERMAT).
@@ -2092,6 +2182,8 @@ struct CoopDev {
     bool inv_fermat;         // a^(p-2) instead of the division-step inversion (cross-check)
     int4* big_state;         // per-check state of a whole super-chunk (7.9 KB per check)
     size_t big_state_bytes;
+    int4* vscratch;          // k_g2_valid_fast3: Montgomery limbs of the affine points (2 values x 4 quads per lane)
+    size_t vscratch_bytes;
     hipEvent_t ready;
 };
 
@@ -2210,6 +2302,7 @@ void coop_free(CoopState* st) {
     }
     if (d->consts) (void)hipFree(d->consts);
     if (d->big_state) (void)hipFree(d->big_state);
+    if (d->vscratch) (void)hipFree(d->vscratch);
     for (int i = 0; i < MAX_PIPES; i++) {
         if (d->pipe[i].lines) (void)hipFree(d->pipe[i].lines);
         if (d->pipe[i].state) (void)hipFree(d->pipe[i].state);
@@ -2630,17 +2723,28 @@ hipError_t coop_g1_valid(const uint64_t* g1, const uint8_t* inf, size_t n, uint8
     hipLaunchKernelGGL(k_g1_valid28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, inf, (uint32_t)n, status, 0);
     return hipGetLastError();
 }
-hipError_t coop_g2_valid(const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s) {
+hipError_t coop_g2_valid(CoopState* st, const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s) {
     if (!n) return hipSuccess;
 #if ZKP_VALID_ASM
     if (!valid_generic_only()) {
-        hipLaunchKernelGGL(k_g2_valid_fast, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 2 * 4 * 64 * sizeof(int4), s, g2, inf, (uint32_t)n, status);
-        hipError_t e = hipGetLastError();
+        // ZKP_G2_VALID_WAVES=2 (environment, read once): the two-wave kernel (no scratch buffer), the A/B baseline of the three-wave one
+        static const bool two_waves = getenv("ZKP_G2_VALID_WAVES") && atoi(getenv("ZKP_G2_VALID_WAVES")) == 2;
+        const unsigned blocks = (unsigned)((2 * n + 63) / 64);
+        hipError_t e;
+        if (two_waves) {
+            hipLaunchKernelGGL(k_g2_valid_fast, dim3(blocks), dim3(64), 2 * 4 * 64 * sizeof(int4), s, g2, inf, (uint32_t)n, status);
+        } else {
+            CoopDev* d = (CoopDev*)st->d_prog;
+            if ((e = ensure_buf(&d->vscratch, &d->vscratch_bytes, (size_t)blocks * 64 * 8 * sizeof(int4))) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_g2_valid_fast3, dim3(blocks), dim3(64), 3 * 4 * 64 * sizeof(int4), s, g2, inf, (uint32_t)n, status, d->vscratch);
+        }
+        e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_g2_valid28, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, g2, inf, (uint32_t)n, status, 1);
         return hipGetLastError();
     }
 #endif
+    (void)st;
     hipLaunchKernelGGL(k_g2_valid28, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, g2, inf, (uint32_t)n, status, 0);
     return hipGetLastError();
 }

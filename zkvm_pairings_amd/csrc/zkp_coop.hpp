@@ -25,7 +25,8 @@ bool coop_supports_k(size_t k);
 hipError_t coop_fp28_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, hipStream_t s);
 // G1/G2 is_valid on the 28-bit core (status 0 / 1 / 2)
 hipError_t coop_g1_valid(const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s);
-hipError_t coop_g2_valid(const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s);
+// st: the context's cooperative state (the three-wave G2 kernel keeps the affine points' limbs in a scratch buffer of its own)
+hipError_t coop_g2_valid(CoopState* st, const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* status, hipStream_t s);
 hipError_t coop_g1_mul(const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf, hipStream_t s);
 hipError_t coop_g2_mul(const uint64_t* base, size_t stride, const uint64_t* sc, size_t n, uint64_t* out, uint8_t* out_inf, hipStream_t s);
 // one tower operation per record (zkp_tower_op_batch); ab = n a-records followed by n b-records

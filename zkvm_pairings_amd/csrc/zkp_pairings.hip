@@ -917,7 +917,7 @@ static int valid_dev(zkp_ctx* c, int which, const void* pts, const void* inf, si
     if (!n) return ZKP_OK;
     if (zkp::coop_selected(&c->coop, c->kernel)) {
         HIPCHK(c, which == 1 ? zkp::coop_g1_valid((const uint64_t*)pts, (const uint8_t*)inf, n, (uint8_t*)status, s)
-                             : zkp::coop_g2_valid((const uint64_t*)pts, (const uint8_t*)inf, n, (uint8_t*)status, s));
+                             : zkp::coop_g2_valid(&c->coop, (const uint64_t*)pts, (const uint8_t*)inf, n, (uint8_t*)status, s));
         return ZKP_OK;
     }
     if (which == 1)
