@@ -50,6 +50,10 @@ for which, fn in (("g1", o.g1_is_valid), ("g2", o.g2_is_valid)):
     c5[which] = {"decode_status_equal_expectation": r[which + "_decode_status_equal"], "valid_status_equal_expectation": r[which + "_valid_status_equal"],
                  "class_counts": r[which + "_class_counts"], "sha256_status": r[which + "_sha256_status"], "oracle_sample": int(len(st)),
                  "oracle_sample_equal": [fn(p, int(i)) for p, i in zip(pts, inf)] == st.tolist()}
+# round 4: the same points through ONE call (zkp_points_check_batch / _dev): 2^20 two-pair checks built from the same byte strings
+c5["one_call"] = {"status_bytes_equal_expectation": r["one_call_status_equal"], "ok_bytes_equal_expectation": r["one_call_ok_equal"],
+                  "resident_flavour_equal": r["one_call_dev_equal"], "checks_that_pass": r["one_call_n_ok"], "and_flag": r["one_call_all_ok"],
+                  "good_subset_and_flag_true": r["one_call_good_subset_all_ok"], "sha256_status_and_ok": r["one_call_sha256"]}
 c5["seconds"] = round(time.time() - t, 1)
 out["config5"] = c5
 flat = json.dumps(out)
