@@ -178,10 +178,12 @@ def main():
     # what a Rust / C host runs, librccl linked into libzkp_pairings.so), outside the timed region and behind a watchdog: a hang or
     # an error here costs the line one field, never the measurement above
     abi_coll, abi_hung = None, False
-    if world > 1 and backend == "nccl" and not shared_gpu:
+    # (ZKP_BENCH_FORCE_ABI_PROBE=1: run the probe on a single rank too - a one-rank communicator; the GPU suite's rehearsal of this code)
+    if (world > 1 and backend == "nccl" and not shared_gpu) or (world == 1 and os.environ.get("ZKP_BENCH_FORCE_ABI_PROBE") == "1"):
         import threading
         uid = [z.PairingEngine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0, device=dev)
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0, device=dev)
         res = {}
 
         def abi_probe():
@@ -211,6 +213,16 @@ def main():
         th.join(90)
         abi_hung = th.is_alive()
         abi_coll = {"ok": False, "error": "no answer within 90 s"} if abi_hung else dict(res)
+        # every rank leaves the same way: if any rank's probe is stuck, all skip the orderly shutdown below
+        abi_coll["ranks_ok"] = (1 if abi_coll.get("ok") else 0) if world == 1 else None
+        if world > 1:
+            hung_any = torch.tensor([1 if abi_hung else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(hung_any, op=dist.ReduceOp.MAX)
+            abi_hung = bool(hung_any.item())
+            if not abi_hung:
+                oks = torch.tensor([1 if abi_coll.get("ok") else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(oks, op=dist.ReduceOp.SUM)
+                abi_coll["ranks_ok"] = int(oks.item())
         abi_coll["what"] = ("the path's one collective through the C ABI: zkp_comm_init_rank on %d ranks, 8 x zkp_and_allreduce_dev (mean ms), one "
                             "zkp_pairing_check_batch_allreduce_dev of 4096 pairs per rank; rank 0's view" % world)
 

@@ -209,6 +209,19 @@ eng.close(); print("ABI COMM OK")
     assert out.returncode == 0 and "ABI COMM OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
 
+def test_bench_abi_collective_probe_on_one_rank():
+    """bench.py's probe of the C-ABI collective (what every rank of an N > 1 run executes behind the timed region), rehearsed on
+    one rank: communicator of one, 8 all-reduces, one zkp_pairing_check_batch_allreduce_dev, the outcome in the JSON line"""
+    import json
+    env = dict(os.environ, ZKP_BENCH_FORCE_ABI_PROBE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--pairs", "32768", "--bare"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    probe = line["abi_collective"]
+    assert probe["ok"] is True and probe["ranks_ok"] == 1 and probe["check_flag"] == 0 and probe["and_of_ones"] == 1 and probe["allreduce_ms"] > 0
+
+
 def test_pairing_over_several_contexts_from_c(tmp_path):
     """integration/c/zkp_multi.c: zkp_pairing_batch_multi / zkp_pairing_check_batch_multi with three contexts (all on
     device 0 of a one-GPU box) against the single-context calls, from plain C."""
