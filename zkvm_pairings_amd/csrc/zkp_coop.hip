@@ -2705,7 +2705,7 @@ hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, hip
 }
 
 // ZKP_VALID_GENERIC=1 (environment, read once): the compiled kernels alone, the round-3 path - the A/B baseline and the cross-check
-static bool valid_generic_only() {
+[[maybe_unused]] static bool valid_generic_only() {
     static const bool v = getenv("ZKP_VALID_GENERIC") && atoi(getenv("ZKP_VALID_GENERIC")) != 0;
     return v;
 }
