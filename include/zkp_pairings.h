@@ -276,6 +276,12 @@ int zkp_pairing_check_batch_allreduce(zkp_ctx* ctx, const uint64_t* g1, const ui
 /* d_all_ok (one int32, required) receives the AND over all ranks; asynchronous on `stream` */
 int zkp_pairing_check_batch_allreduce_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1, const void* d_inf2,
                                           size_t n_checks, size_t k, void* d_ok, void* d_all_ok, void* stream);
+/* BASELINE config 5 on a node ("subgroup check + pairing on raw points, 8 GPUs"): this rank's block of zkp_points_check_batch, then the
+ * same ONE all-reduce of the AND flag; status and ok bytes stay per rank.  d_all_ok / all_ok are required. */
+int zkp_points_check_batch_allreduce(zkp_ctx* ctx, const uint8_t* g1_bytes, const uint8_t* g2_bytes, size_t n_checks, size_t k, uint8_t* st1,
+                                     uint8_t* st2, uint8_t* ok, int* all_ok);
+int zkp_points_check_batch_allreduce_dev(zkp_ctx* ctx, const void* d_g1_bytes, const void* d_g2_bytes, size_t n_checks, size_t k,
+                                         void* d_st1, void* d_st2, void* d_ok, void* d_all_ok, void* stream);
 /* SURVEY.md 8e variant, ONE product check over the whole sharded batch: this rank's zkp_miller_product, ONE ncclAllGather of
  * 576 B per rank, the product of the gathered values and ONE final exponentiation on every rank (identical results):
  * *is_one = (prod over ALL ranks' pairs of e(P_i, Q_i) == Gt::identity()); out_gt (72 u64) may be NULL. */

@@ -135,6 +135,11 @@ extern "C" {
     pub fn zkp_pairing_check_batch_allreduce_dev(ctx: *mut ZkpCtx, d_g1: *const c_void, d_g2: *const c_void, d_inf1: *const c_void,
                                                  d_inf2: *const c_void, n_checks: usize, k: usize, d_ok: *mut c_void,
                                                  d_all_ok: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn zkp_points_check_batch_allreduce(ctx: *mut ZkpCtx, g1_bytes: *const u8, g2_bytes: *const u8, n_checks: usize, k: usize, st1: *mut u8,
+                                            st2: *mut u8, ok: *mut u8, all_ok: *mut c_int) -> c_int;
+    pub fn zkp_points_check_batch_allreduce_dev(ctx: *mut ZkpCtx, d_g1_bytes: *const c_void, d_g2_bytes: *const c_void, n_checks: usize,
+                                                k: usize, d_st1: *mut c_void, d_st2: *mut c_void, d_ok: *mut c_void,
+                                                d_all_ok: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn zkp_pairing_product_check_allgather(ctx: *mut ZkpCtx, g1: *const u64, g2: *const u64, inf1: *const u8, inf2: *const u8,
                                                n: usize, out_gt: *mut u64, is_one: *mut c_int) -> c_int;
     pub fn zkp_take_validation_status_dev(ctx: *mut ZkpCtx, stream: *mut c_void, bad: *mut c_int) -> c_int;
@@ -368,6 +373,21 @@ impl Engine {
             zkp_pairing_check_batch_allreduce(self.0, g1.as_ptr(), g2.as_ptr(), opt_ptr(inf1), opt_ptr(inf2), n / k, k, ok.as_mut_ptr(), &mut all)
         };
         if rc == ZKP_OK { Ok((ok, all != 0)) } else { Err(self.err(rc)) }
+    }
+
+    /// config 5 on a node: this rank's block of `points_check_batch` + the AND over all ranks
+    #[allow(clippy::type_complexity)]
+    pub fn points_check_batch_allreduce(&mut self, g1_bytes: &[u8], g2_bytes: &[u8], k: usize) -> Result<(Vec<u8>, Vec<u8>, Vec<u8>, bool), Error> {
+        if g1_bytes.len() % 96 != 0 || g2_bytes.len() != 2 * g1_bytes.len() || k == 0 || (g1_bytes.len() / 96) % k != 0 {
+            return Err(Error { status: ZKP_ERR_ARG, detail: "byte string lengths / k".into() });
+        }
+        let n = g1_bytes.len() / 96;
+        let (mut st1, mut st2, mut ok) = (vec![0u8; n], vec![0u8; n], vec![0u8; n / k]);
+        let mut all: c_int = 1;
+        let rc = unsafe {
+            zkp_points_check_batch_allreduce(self.0, g1_bytes.as_ptr(), g2_bytes.as_ptr(), n / k, k, st1.as_mut_ptr(), st2.as_mut_ptr(), ok.as_mut_ptr(), &mut all)
+        };
+        if rc == ZKP_OK { Ok((st1, st2, ok, all != 0)) } else { Err(self.err(rc)) }
     }
 
     /// ONE product check over the whole sharded batch: this rank's Miller product, one all-gather of 576 B per rank, one final

@@ -197,6 +197,12 @@ ok, flag = eng.pairing_check_allreduce(t1, t2, 2)
 torch.cuda.synchronize()
 assert bool(ok.all().item()) and int(flag.item()) == 1
 f = torch.zeros(1, dtype=torch.int32, device="cuda"); eng.and_allreduce(f); assert int(f.item()) == 0
+B1, B2 = configs.to_bytes(G1, 1), configs.to_bytes(G2, 2)
+s1, s2, okb, allb = eng.points_check_allreduce(B1, B2, 2)
+assert not s1.any() and not s2.any() and okb.all() and allb is True
+B1[3, 5] ^= 1
+s1, s2, okb, allb = eng.points_check_allreduce(B1, B2, 2)
+assert s1[3] == 3 and okb[1] == 0 and okb.sum() == len(okb) - 1 and allb is False
 gt, one = eng.pairing_product_check_allgather(G1, G2)
 assert one and np.array_equal(gt, eng.gt_identity())
 gt2, one2 = eng.pairing_product_check(g1, g2)

@@ -1526,6 +1526,32 @@ int zkp_pairing_check_batch_allreduce(zkp_ctx* c, const uint64_t* g1, const uint
     *all_ok = all;
     return rc_local;
 }
+int zkp_points_check_batch_allreduce_dev(zkp_ctx* c, const void* b1, const void* b2, size_t n_checks, size_t k, void* st1, void* st2, void* ok,
+                                         void* all_ok, void* stream) {
+    if (!c || !all_ok) return ZKP_ERR_ARG;
+    if (!c->comm) { c->err = "no communicator: call zkp_comm_init_rank first"; return ZKP_ERR_COMM; }
+    int rc = zkp_points_check_batch_dev(c, b1, b2, n_checks, k, st1, st2, ok, all_ok, stream);
+    if (rc) return rc;
+    return and_allreduce(c, (int*)all_ok, S(stream));
+}
+int zkp_points_check_batch_allreduce(zkp_ctx* c, const uint8_t* b1, const uint8_t* b2, size_t n_checks, size_t k, uint8_t* st1, uint8_t* st2,
+                                     uint8_t* ok, int* all_ok) {
+    if (!c || !all_ok) return ZKP_ERR_ARG;
+    if (!c->comm) { c->err = "no communicator: call zkp_comm_init_rank first"; return ZKP_ERR_COMM; }
+    int local = 1;
+    const int rc_local = zkp_points_check_batch(c, b1, b2, n_checks, k, st1, st2, ok, &local);
+    if (rc_local) local = 0;     // a rank that failed locally still takes part, with flag 0: no peer hangs
+    int rc = bind(c);
+    if (rc) return rc;
+    HostCall drain(c);
+    HIPCHK(c, hipMemcpyAsync(c->d_flag + 1, &local, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if ((rc = and_allreduce(c, c->d_flag + 1, c->stream))) return rc;
+    int all = 0;
+    HIPCHK(c, hipMemcpyAsync(&all, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *all_ok = all;
+    return rc_local;
+}
 int zkp_pairing_product_check_allgather(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n,
                                         uint64_t* out_gt, int* is_one) {
     if (!c || (n && (!g1 || !g2)) || n > 0x7fffffffu) return ZKP_ERR_ARG;

@@ -390,6 +390,18 @@ class PairingEngine:
         self._chk(self._lib.zkp_pairing_check_batch_allreduce(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n // k, k, _ptr(ok), ctypes.byref(allok)))
         return ok, bool(allok.value)
 
+    def points_check_allreduce(self, g1_bytes, g2_bytes, k):
+        """config 5 on a node: this rank's block of points_check + the AND over all ranks (host arrays) -> (st1, st2, ok, all_ok)"""
+        b1 = np.ascontiguousarray(g1_bytes, dtype=np.uint8).reshape(-1, 96)
+        b2 = np.ascontiguousarray(g2_bytes, dtype=np.uint8).reshape(-1, 192)
+        n = b1.shape[0]
+        if b2.shape[0] != n or k <= 0 or n % k:
+            raise ValueError("byte strings / k do not match")
+        s1, s2, okb = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8), np.empty(n // k, dtype=np.uint8)
+        allok = ctypes.c_int(1)
+        self._chk(self._lib.zkp_points_check_batch_allreduce(self._h, _ptr(b1), _ptr(b2), n // k, k, _ptr(s1), _ptr(s2), _ptr(okb), ctypes.byref(allok)))
+        return s1, s2, okb, bool(allok.value)
+
     def pairing_product_check_allgather(self, g1, g2, inf1=None, inf2=None):
         g1, g2 = _np(g1, 12), _np(g2, 24)
         n = g1.shape[0]
