@@ -766,6 +766,35 @@ def test_chunk_and_group_boundaries(monkeypatch):
         e.close()
 
 
+def test_phase_c_in_parts_gives_the_same_gt(eng):
+    """ZKP_COOP_C_SPLIT (phase C of a super-chunk in parts on the pipelines' streams - an experiment knob, off by default): the same
+    Gt and flags as the single launch sequence, on a ragged batch that spans several chunks"""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from zkvm_pairings_amd import synthetic
+    n = (1 << 17) + 333
+    g1, g2, _, _ = synthetic.random_pairs(eng, n, seed=0xC5)
+    inf1 = np.zeros(n, dtype=np.uint8)
+    inf1[[0, 70000, n - 1]] = 1
+    want = eng.pairing(g1, g2, inf1, None)
+    ok, allok = eng.pairing_check(g1, g2, 1, inf1, None)
+    digest = hashlib.sha256(want.tobytes() + ok.tobytes()).hexdigest()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+        "import zkvm_pairings_amd as z\nfrom zkvm_pairings_amd import synthetic\n"
+        "e = z.PairingEngine(0)\nn = %d\ng1, g2, _, _ = synthetic.random_pairs(e, n, seed=0xC5)\n"
+        "inf1 = np.zeros(n, dtype=np.uint8); inf1[[0, 70000, n - 1]] = 1\n"
+        "gt = e.pairing(g1, g2, inf1, None); ok, allok = e.pairing_check(g1, g2, 1, inf1, None)\n"
+        "print('DIGEST', hashlib.sha256(gt.tobytes() + ok.tobytes()).hexdigest(), int(allok))\n" % (root, n))
+    for parts in ("2", "3"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKP_COOP_C_SPLIT=parts), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-1500:]
+        assert "DIGEST %s %d" % (digest, int(allok)) in out.stdout, (parts, out.stdout[-300:])
+
+
 def test_final_exponentiation_of_arbitrary_fp12(keng):
     """final_exponentiation must agree with the oracle on ANY invertible Fp12 (not only Miller outputs),
     including 1, -1, elements of Fp / Fp2 / Fp6 embedded in Fp12 and limbs at the top of the range."""
