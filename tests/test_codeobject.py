@@ -45,3 +45,12 @@ def test_hot_kernels_keep_their_registers():
     for name in ("k_g1_valid28", "k_g2_valid28"):
         (v,) = find(name)
         assert v["spill"] == 0, (name, v)
+    # round 4: the upstream-shaped line steps are asm too (no spilled register, no scratch: the compiled steps had 42 and 128 B);
+    # the asm subgroup checks fit three waves per SIMD (what they spill sits in the prologue / epilogue around the step loop)
+    (prepf,) = find("k_prep_linesILb0E")
+    assert prepf["vgpr"] <= 256 and prepf["spill"] == 0 and prepf["scratch"] == 0, prepf
+    for name in ("k_g1_valid_fastE", "k_g2_valid_fast3E"):
+        (v,) = find(name)
+        assert v["vgpr"] <= 168, (name, v)
+    (v,) = find("k_g2_valid_fastE")
+    assert v["vgpr"] <= 256 and v["spill"] == 0, v
