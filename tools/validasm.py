@@ -112,20 +112,27 @@ class FpStep:
         self.e("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (self.vlds, self.vlds))
         self.e("v_lshlrev_b32 v%d, 4, v%d" % (self.vlds, self.vlds))
 
-    def lds_read(self, dst, slot):
-        """LDS slot (limb quad q of slot v at (v * 4 + q) * 1024 + lane * 16: the layout of valid_park) -> 14 registers"""
+    def lds_read(self, dst, slot, wait=True):
+        """LDS slot (limb quad q of slot v at (v * 4 + q) * 1024 + lane * 16: the layout of valid_park) -> 14 registers.
+        wait=False: the caller places lds_wait() in front of the first use (the transfer then runs under the instructions between)"""
         self.lds_addr()
         for q in range(3):
             self.e("ds_read_b128 v[%d:%d], v%d offset:%d" % (dst + 4 * q, dst + 4 * q + 3, self.vlds, (slot * 4 + q) * 1024))
         self.e("ds_read_b64 v[%d:%d], v%d offset:%d" % (dst + 12, dst + 13, self.vlds, (slot * 4 + 3) * 1024))
-        self.e("s_waitcnt lgkmcnt(0)")
+        if wait:
+            self.lds_wait()
 
-    def lds_write(self, src, slot):
+    def lds_write(self, src, slot, wait=True):
+        """wait=False: the caller guarantees an lds_wait() in front of the next write to the source registers"""
         self.lds_addr()
         for q in range(3):
             self.e("ds_write_b128 v%d, v[%d:%d] offset:%d" % (self.vlds, src + 4 * q, src + 4 * q + 3, (slot * 4 + q) * 1024))
         self.e("ds_write_b64 v%d, v[%d:%d] offset:%d" % (self.vlds, src + 12, src + 13, (slot * 4 + 3) * 1024))
-        self.e("s_waitcnt lgkmcnt(0)")    # the source registers are about to be reused
+        if wait:
+            self.lds_wait()    # the source registers are about to be reused
+
+    def lds_wait(self):
+        self.e("s_waitcnt lgkmcnt(0)")
 
 
 QX, QY, PARK = 0, 1, 2      # LDS slots of the G1 kernel
@@ -315,10 +322,13 @@ class Fp2Step3(FpStep):
         self.mov(y, a)
         self.all_lanes()
 
-    def mul_acc(self, a, b, ra, rb, first, la, lb, restore):
+    def mul_acc(self, a, b, ra, rb, first, la, lb, restore, b_in_flight=False):
         """the lazy accumulation (+)= coefficient c of a b: c = 0: a b - a' b', c = 1: a b' + a' b.  ra, rb: blocks for the partner's
-        values.  On c = 1 lanes b and b' change places for the products (v_swap); restore puts b back."""
+        values.  On c = 1 lanes b and b' change places for the products (v_swap); restore puts b back.
+        b_in_flight: b is still arriving from LDS - the wait sits behind the first operand's exchange"""
         self.swap(ra, a)
+        if b_in_flight:
+            self.lds_wait()
         self.swap(rb, b)
         self.lanes(1)
         for i in range(NL):
@@ -359,15 +369,16 @@ def g2_dbl3(vb=6):
     R0, R1, R2, R3, R4 = g.R
     D = g.D
     g.prologue()
-    g.lds_read(R2, LZ)
+    g.lds_read(R2, LZ, wait=False)        # Z arrives under the forming of 2Y and its exchange
     g.shl(R3, R1, 1)
-    g.mul_acc(R3, R2, R4, R0, True, 2, 1, False)
+    g.mul_acc(R3, R2, R4, R0, True, 2, 1, False, b_in_flight=True)
     tail(g, R2)                           # Z' = (2Y) Z
-    g.lds_write(R2, LZ)
+    g.lds_write(R2, LZ, wait=False)       # (R2 is next written by M's reduction, behind the wait for X)
     g.forms(R1, R4, R3)
+    g.lds_read(R1, LX, wait=False)        # Y is dead behind its operand forms: X arrives under B's product and reduction
     g.prod(R4, R3, True, 2, 2)
     tail(g, R0)                           # B = Y^2
-    g.lds_read(R1, LX)
+    g.lds_wait()
     g.forms(R1, R4, R3)
     g.times3(R3, R3)
     g.prod(R4, R3, True, 2, 6)
