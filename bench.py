@@ -320,7 +320,7 @@ def main():
                        "kernel": "k_g1_valid_fast (asm doubling / addition steps, 3 waves per SIMD) + k_g1_valid28 on the points it marks"},
                 "g2": {"ms": v2_ms, "points_per_s": n / v2_ms * 1e3, "fp_mul_equivalents_per_point": FPMUL_G2_VALID,
                        "frac": n * FPMUL_G2_VALID * MACS_PER_FPMUL / (v2_ms * 1e-3) / PEAK_MACS,
-                       "kernel": "k_g2_valid_fast (asm steps, two lanes per point) + k_g2_valid28 on the points it marks"},
+                       "kernel": "k_g2_valid_fast3 (asm steps, two lanes per point, 3 waves per SIMD: X / Z of the running point in LDS) + k_g2_valid28 on the points it marks"},
                 "macs_source": "bench.py FPMUL_G1_VALID / FPMUL_G2_VALID: doubling 2M + 5S, mixed addition 7M + 4S of the inversion-free Jacobian form "
                                "(Fp2: M = 4, S = 2 Fp mul), G1 two chains of 63 + 5 steps, G2 one, + curve equation / endomorphism / comparison, x 300; "
                                "recomputable from profiles/r04/workloads_a.json (roofline.config5_*)",

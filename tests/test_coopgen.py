@@ -242,6 +242,19 @@ def test_program_encoding_is_consistent():
             assert f.read() == open(tf.name).read(), "run tools/coopgen.py to regenerate zkp_coop_prog.inc"
 
 
+def test_executed_multiply_add_count():
+    """tools/executed_macs.py (what bench.py prints as executed_macs_per_pairing): the generators' own counts, below the algorithmic
+    6.56 M of SURVEY 8(d) and dominated by the Miller program and the compressed squarings"""
+    import executed_macs
+    r = executed_macs.per_pairing()
+    assert abs(r["total"] - sum(v for k, v in r.items() if k != "total")) < 1
+    assert 4.5e6 < r["total"] < 5.6e6 < 6560700
+    assert r["k_coop miller1"] > r["k_ksq"] > r["k_coop fexp_c step programs"] > r["k_prep_lines<true>"] > r["k_coop fexp_a"]
+    # a Karatsuba block is 147 multiply-adds, a reduction 196: the Fp12 product step of the interpreter
+    prod = [st for st in cg.prog_tower("fp12_mul").steps if st["op"] == cg.OP_MULACC and st["T"] == 12]
+    assert prod and executed_macs.program_macs_per_lane(prod) == len(prod) * (12 * 147 + 196)
+
+
 def test_division_step_inversion_model():
     """tools/safegcd_model.py: the limb-exact model of the kernels' Fp inversion (f_inv in zkp_coop.hip) against pow(x, -1, p);
     its constants are the ones tools/gen_constants.py writes into zkp_constants28.h"""

@@ -143,6 +143,34 @@ def test_points_check_small_cases_vs_oracle(eng):
     assert not s1.any() and not s2.any() and ok.tolist() == [1] and allok
 
 
+def test_new_entry_points_reject_bad_arguments(eng):
+    """status codes instead of crashes: null pointers, mismatched sizes, a collective without a communicator"""
+    import ctypes
+    from zkvm_pairings_amd import _lib
+    lib, h = eng._lib, eng._h
+    b = np.zeros(96, dtype=np.uint8)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    allok = ctypes.c_int(7)
+    assert lib.zkp_points_check_batch(h, None, None, 1, 1, None, None, None, ctypes.byref(allok)) == -1
+    assert lib.zkp_points_check_batch(h, None, None, 0, 1, None, None, None, ctypes.byref(allok)) == 0 and allok.value == 1
+    assert lib.zkp_points_check_batch(None, p(b), p(b), 1, 1, None, None, None, None) == -1
+    assert lib.zkp_g1_decode_batch_dev(h, None, 4, None, None, None, None) == -1
+    assert lib.zkp_and_allreduce_dev(h, None, None) == -1
+    assert lib.zkp_comm_init_rank(h, 0, 0, b"\0" * 128) == -1 and lib.zkp_comm_init_rank(h, 2, 2, b"\0" * 128) == -1
+    assert lib.zkp_comm_unique_id(None) == -1
+    g1 = np.zeros(12, dtype=np.uint64)
+    g2 = np.zeros(24, dtype=np.uint64)
+    assert lib.zkp_pairing_check_batch_allreduce(h, p(g1), p(g2), None, None, 1, 1, None, ctypes.byref(allok)) == -6      # ZKP_ERR_COMM
+    assert b"communicator" in lib.zkp_last_error(h)
+    assert lib.zkp_strerror(-6) == b"RCCL error / no communicator"
+    with pytest.raises(ValueError):
+        eng.points_check(np.zeros((3, 96), dtype=np.uint8), np.zeros((2, 192), dtype=np.uint8), 1)
+    with pytest.raises(ValueError):
+        eng.points_check(np.zeros((3, 96), dtype=np.uint8), np.zeros((3, 192), dtype=np.uint8), 2)
+    with pytest.raises(_lib.ZkpError):
+        eng.tower_op(21, np.zeros((1, 72), dtype=np.uint64))
+
+
 def test_codec_on_resident_tensors(eng):
     """zkp_g1/g2_decode_batch_dev / encode_batch_dev: the same bytes and points as the host-pointer codec, aligned and unaligned views"""
     import torch
