@@ -260,7 +260,11 @@ int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1,
  *     every rank: zkp_pairing_check_batch_allreduce(ctx, <its contiguous block of the checks>, ok, &all_ok)
  * = zkp_pairing_check_batch on the rank's block, then ONE ncclAllReduce(count = 1, ncclInt32, ncclMin) of the AND flag on the
  * context's stream (RCCL has no bitwise AND; MIN of {0,1} is AND): *all_ok is the AND over ALL ranks' checks, ok[] stays
- * per-rank.  Nothing else crosses xGMI.  A context holds at most one communicator; zkp_free destroys it.  No reference
+ * per-rank.  Nothing else crosses xGMI.  A context holds at most one communicator; zkp_free destroys it.
+ * Failure on one rank: a rank whose OWN block fails (bad arguments, non-canonical limbs under zkp_set_validate, a HIP error) still
+ * takes part in the collective - with flag 0 (AND-reduce) or the zero record (all-gather variant) - so no peer is left waiting and
+ * every rank reads all_ok / is_one = 0; the failing rank returns its own status afterwards.  Only a call without context,
+ * output flag or communicator returns before the collective (ZKP_ERR_ARG / ZKP_ERR_COMM).  No reference
  * counterpart (the reference is a single-threaded host crate); the torch.distributed flavour of the same step is
  * zkvm_pairings_amd/dist.py. */
 #define ZKP_COMM_ID_BYTES 128

@@ -236,6 +236,28 @@ assert one and np.array_equal(gt, eng.gt_identity())
 gt2, one2 = eng.pairing_product_check(g1, g2)
 gt3, one3 = eng.pairing_product_check_allgather(g1, g2)
 assert np.array_equal(gt2, gt3) and one2 == one3 == False
+# a rank whose own part fails still joins the collective (no peer hangs) with a flag / record that fails the global check, and returns its error
+import ctypes
+lib, h = eng._lib, eng._h
+vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+allok = ctypes.c_int(7)
+assert lib.zkp_pairing_check_batch_allreduce(h, None, vp(G2), None, None, 4, 2, None, ctypes.byref(allok)) == -1 and allok.value == 0
+bad = G1.copy(); bad[0, 5] = 2**64 - 1                       # limbs >= p: with validation on the local call reports ZKP_ERR_NONCANONICAL
+assert lib.zkp_set_validate(h, 1) == 0
+allok = ctypes.c_int(7)
+assert lib.zkp_pairing_check_batch_allreduce(h, vp(bad), vp(G2), None, None, len(G1) // 2, 2, None, ctypes.byref(allok)) == -4 and allok.value == 0
+one = ctypes.c_int(7)
+assert lib.zkp_pairing_product_check_allgather(h, None, vp(G2), None, None, 8, None, ctypes.byref(one)) == -1 and one.value == 0
+assert b"null points" in lib.zkp_last_error(h)
+one = ctypes.c_int(7)
+assert lib.zkp_pairing_product_check_allgather(h, vp(bad), vp(G2), None, None, len(G1), None, ctypes.byref(one)) == -4 and one.value == 0
+assert b"limbs" in lib.zkp_last_error(h) and lib.zkp_set_validate(h, 0) == 0
+dflag = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+rc = lib.zkp_pairing_check_batch_allreduce_dev(h, None, ctypes.c_void_p(t2.data_ptr()), None, None, 4, 2, None, ctypes.c_void_p(dflag.data_ptr()), None)
+torch.cuda.synchronize()
+assert rc == -1 and int(dflag.item()) == 0
+gt, one = eng.pairing_product_check_allgather(G1, G2)          # and the engine still works afterwards
+assert one and np.array_equal(gt, eng.gt_identity())
 eng.comm_destroy(); assert eng.comm_info() == (0, 0)
 eng.close(); print("ABI COMM OK")
 '''

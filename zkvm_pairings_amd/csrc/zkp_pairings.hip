@@ -1491,6 +1491,17 @@ static int and_allreduce(zkp_ctx* c, int* d_flag, hipStream_t s) {
     NCCLCHK(c, ncclAllReduce(d_flag, d_flag, 1, ncclInt32, ncclMin, c->comm, s));
     return ZKP_OK;
 }
+// the collective of the resident flavours after the rank's own work: a local failure turns the rank's flag into 0 and still joins
+static int reduce_after_local(zkp_ctx* c, int rc_local, int* d_all_ok, hipStream_t s) {
+    if (rc_local) {
+        const std::string first = c->err;
+        if (bind(c) != ZKP_OK || hipMemsetAsync(d_all_ok, 0, sizeof(int), s) != hipSuccess) return rc_local;      // nothing left to join with
+        (void)and_allreduce(c, d_all_ok, s);
+        c->err = first;
+        return rc_local;
+    }
+    return and_allreduce(c, d_all_ok, s);
+}
 int zkp_and_allreduce_dev(zkp_ctx* c, void* d_flag, void* stream) {
     if (!c || !d_flag) return ZKP_ERR_ARG;
     int rc = bind(c);
@@ -1501,9 +1512,10 @@ int zkp_pairing_check_batch_allreduce_dev(zkp_ctx* c, const void* g1, const void
                                           void* ok, void* all_ok, void* stream) {
     if (!c || !all_ok) return ZKP_ERR_ARG;
     if (!c->comm) { c->err = "no communicator: call zkp_comm_init_rank first"; return ZKP_ERR_COMM; }
-    int rc = zkp_pairing_check_batch_dev(c, g1, g2, i1, i2, n_checks, k, ok, all_ok, stream);   // a rank with an empty block still sets its flag to 1
-    if (rc) return rc;
-    return and_allreduce(c, (int*)all_ok, S(stream));
+    // a rank with an empty block still sets its flag to 1; a rank whose own block FAILED still takes part, with flag 0, so that no
+    // peer hangs in the collective (every rank then reads 0; this rank returns its own error)
+    const int rc_local = zkp_pairing_check_batch_dev(c, g1, g2, i1, i2, n_checks, k, ok, all_ok, stream);
+    return reduce_after_local(c, rc_local, (int*)all_ok, S(stream));
 }
 int zkp_pairing_check_batch_allreduce(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks,
                                       size_t k, uint8_t* ok, int* all_ok) {
@@ -1530,9 +1542,8 @@ int zkp_points_check_batch_allreduce_dev(zkp_ctx* c, const void* b1, const void*
                                          void* all_ok, void* stream) {
     if (!c || !all_ok) return ZKP_ERR_ARG;
     if (!c->comm) { c->err = "no communicator: call zkp_comm_init_rank first"; return ZKP_ERR_COMM; }
-    int rc = zkp_points_check_batch_dev(c, b1, b2, n_checks, k, st1, st2, ok, all_ok, stream);
-    if (rc) return rc;
-    return and_allreduce(c, (int*)all_ok, S(stream));
+    const int rc_local = zkp_points_check_batch_dev(c, b1, b2, n_checks, k, st1, st2, ok, all_ok, stream);
+    return reduce_after_local(c, rc_local, (int*)all_ok, S(stream));
 }
 int zkp_points_check_batch_allreduce(zkp_ctx* c, const uint8_t* b1, const uint8_t* b2, size_t n_checks, size_t k, uint8_t* st1, uint8_t* st2,
                                      uint8_t* ok, int* all_ok) {
@@ -1554,17 +1565,26 @@ int zkp_points_check_batch_allreduce(zkp_ctx* c, const uint8_t* b1, const uint8_
 }
 int zkp_pairing_product_check_allgather(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n,
                                         uint64_t* out_gt, int* is_one) {
-    if (!c || (n && (!g1 || !g2)) || n > 0x7fffffffu) return ZKP_ERR_ARG;
+    if (!c) return ZKP_ERR_ARG;
     if (!c->comm) { c->err = "no communicator: call zkp_comm_init_rank first"; return ZKP_ERR_COMM; }
+    const bool bad_args = (n && (!g1 || !g2)) || n > 0x7fffffffu;
+    if (bad_args) { n = 0; c->err = "zkp_pairing_product_check_allgather: null points / too many pairs"; }
     int rc = bind(c);
     if (rc) return rc;
     HostCall drain(c);
     const size_t R = (size_t)c->comm_nranks;
-    // this rank's Miller product -> c->prod[0..72) (the identity for an empty block), gathered into slot 5 (R records)
+    // this rank's Miller product -> c->prod[0..72) (the identity for an empty block), gathered into slot 5 (R records).  A rank whose
+    // own part fails still joins the collective - with the ZERO record, so that the product is 0 and every rank reads is_one = 0 (no
+    // peer hangs, none passes a check this rank's pairs never entered) - and returns its own error afterwards.
     Staged st = {nullptr, nullptr, nullptr, nullptr};
-    if (n && (rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st))) return rc;
     if ((rc = ensure_prod(c, (n / 8 + 1 > R ? n / 8 + 1 : R))) || (rc = ensure(c, 5, R * 576)) || (rc = ensure(c, 4, 576))) return rc;
-    if ((rc = miller_product_dev(c, st.g1, st.g2, st.i1, st.i2, n, n ? nullptr : c->prod, c->stream))) return rc;
+    int rc_local = bad_args ? ZKP_ERR_ARG : ZKP_OK;
+    if (!rc_local && n) rc_local = stage_pairs(c, g1, g2, inf1, inf2, n, &st);
+    if (!rc_local) rc_local = miller_product_dev(c, st.g1, st.g2, st.i1, st.i2, n, n ? nullptr : c->prod, c->stream);
+    const std::string first = c->err;
+    if (rc_local) {
+        if (bind(c) != ZKP_OK || hipMemsetAsync(c->prod, 0, 576, c->stream) != hipSuccess) return rc_local;
+    }
     NCCLCHK(c, ncclAllGather(c->prod, c->buf[5], 72, ncclUint64, c->comm, c->stream));
     uint64_t* const total = c->prod + 72 * R;      // a spare record (ensure_prod keeps two behind the R the tree works on)
     if ((rc = fp12_product_dev(c, (const uint64_t*)c->buf[5], R, total, c->stream))) return rc;
@@ -1576,7 +1596,8 @@ int zkp_pairing_product_check_allgather(zkp_ctx* c, const uint64_t* g1, const ui
     HIPCHK(c, hipMemcpyAsync(&one, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (is_one) *is_one = one;
-    return ZKP_OK;
+    if (rc_local) c->err = first;
+    return rc_local;
 }
 
 // page-locked host memory for the host-pointer entry points (header: "pinned host memory")
