@@ -89,6 +89,52 @@ def test_sharded_product_check_gathers_every_rank_part_gloo():
     assert parts == [want, want] and flags == [True, True]      # both ranks see both parts, in rank order
 
 
+def _worker_failing(rank, ws, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from zkvm_pairings_amd import dist as zd
+
+    def check_fn(lo, hi):
+        if rank == 1:
+            raise RuntimeError("rank 1's own block failed")
+        return torch.ones(1, dtype=torch.int32)
+
+    def miller_product_fn(lo, hi):
+        if rank == 1:
+            raise RuntimeError("rank 1's own block failed")
+        return torch.arange(1, 73, dtype=torch.int64)
+
+    out = []
+    for call in (lambda: zd.sharded_pairing_check(check_fn, 1001, torch.device("cpu")),
+                 lambda: zd.sharded_product_check(miller_product_fn, lambda parts: bool((parts != 0).any(dim=1).all()), 1001)):
+        try:
+            out.append(call())
+        except RuntimeError as e:
+            out.append(str(e))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_still_joins_the_collective_gloo():
+    """a rank whose own block raises takes part with flag 0 / the zero record: the peer gets False (no hang), the failing rank its error"""
+    ws = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_failing, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(ws))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == [False, False]
+    assert got[1] == ["rank 1's own block failed"] * 2
+
+
 def test_shard_range_partitions():
     from zkvm_pairings_amd.dist import shard_range
     for n in (0, 1, 7, 8, 1 << 20, (1 << 20) + 5):

@@ -71,10 +71,13 @@ def sharded_pairing_check(check_fn, n_checks, device):
     Returns the global AND as a python bool on every rank."""
     rank, ws = world()
     lo, hi = shard_range(n_checks, rank, ws)
-    if hi > lo:
-        flag = check_fn(lo, hi)
-    else:
-        flag = torch.ones(1, dtype=torch.int32, device=device)
+    try:
+        flag = check_fn(lo, hi) if hi > lo else torch.ones(1, dtype=torch.int32, device=device)
+    except Exception:
+        # a rank whose own block fails still joins the collective - with flag 0 - so that no peer waits for it and every rank
+        # reads False; the failure is raised here afterwards (the C ABI's zkp_pairing_check_batch_allreduce does the same)
+        and_reduce(torch.zeros(1, dtype=torch.int32, device=device))
+        raise
     and_reduce(flag)
     return bool(flag.item())
 
@@ -99,4 +102,11 @@ def sharded_product_check(miller_product_fn, finish_fn, n_pairs):
     identity (engine.fp12_product + engine.final_exponentiation).  Every rank returns the same bool."""
     rank, ws = world()
     lo, hi = shard_range(n_pairs, rank, ws)
-    return bool(finish_fn(gather_parts(miller_product_fn(lo, hi))))
+    try:
+        part = miller_product_fn(lo, hi)
+    except Exception:
+        # as above: the failing rank contributes the ZERO record (product 0, never the identity: every rank reads False) and raises
+        dev = "cpu" if not _active() or _host_backend() else torch.device("cuda", torch.cuda.current_device())
+        gather_parts(torch.zeros(72, dtype=torch.int64, device=dev))
+        raise
+    return bool(finish_fn(gather_parts(part)))
