@@ -826,6 +826,7 @@ def sqr_run(b, v, n):
 X_BITS = [i for i in range(64) if (M.BLS_X >> i) & 1]       # 16, 48, 57, 60, 62, 63
 KSQ_NSQ = X_BITS[-1]                                         # squarings of one x-power run
 KSQ_MASK = sum(1 << (e - 1) for e in X_BITS)                 # snapshot after squaring number e (loop index e - 1)
+KSQ_SPLIT = int(os.environ.get("ZKP_GEN_KSQ_SPLIT", "3"))    # set bits of |x| the compressed run covers (6: all of them - rounds 2-3)
 
 
 def cyc_exp(b, a, park, half=False):
@@ -845,11 +846,21 @@ def cyc_exp(b, a, park, half=False):
         assert all(s == 1 for s in signs) and kb <= Builder.K_INPUT
     bits = [e - 1 for e in X_BITS] if half else X_BITS
     assert bits[0] >= 1
-    n = len(bits)
-    b.cut([(PLAN_KSQ, park, ST_SNAP, bits[-1], sum(1 << (e - 1) for e in bits)), (PLAN_KDEC_A, ST_SNAP, n, ST_KN),
+    # the compressed run covers the first KSQ_SPLIT set bits (16, 48, 57); the squarings above its last snapshot (six, with a
+    # product after the third, fifth and sixth) are Granger-Scott squarings of the step program on the decompressed value: three
+    # snapshots + decompressions instead of six per run
+    n = min(KSQ_SPLIT, len(bits))
+    b.cut([(PLAN_KSQ, park, ST_SNAP, bits[n - 1], sum(1 << (e - 1) for e in bits[:n])), (PLAN_KDEC_A, ST_SNAP, n, ST_KN),
            (PLAN_INV, ST_KN, ST_KNINV, n), (PLAN_KDEC_B, ST_SNAP, n, ST_KNINV)])
     snap = lambda k: (ST_SNAP + 12 * k, [1] * 12, Builder.K_REDUCED)
     r = b.fill(snap(n - 1))
+    if n < len(bits):
+        sq = None
+        for e in range(bits[n - 1] + 1, bits[-1] + 1):
+            sq = b.cyclotomic_sqr(b.alloc(12), r) if sq is None else b.cyclotomic_sqr(sq, sq)
+            if e in bits:
+                r = b.fp12_mul(r, r, sq)
+        b.release(sq.slots)
     for k in range(n - 2, -1, -1):
         s = b.fill(snap(k))
         r = b.fp12_mul(r, r, s)
