@@ -453,7 +453,7 @@ def main():
                                                      "what": "fexp_a, k_batch_inv, the phase C plan (see profiles/r04/*_kernel_stats.txt for its split)"}},
                 "launch": "one pass over the resident batch = phase A per 2^16-check chunk on two overlapped HIP streams (k_prep_lines, k_coop "
                           "miller, k_coop fexp_a), ONE k_batch_inv, then the phase C plan over the whole shard: six step programs "
-                          "alternating with five compressed squaring runs (k_ksq) and their decompression (k_kdec_a, k_batch_inv, "
+                          "alternating with five compressed squaring runs (k_ksq: 57 squarings, 3 snapshots each) and their decompression (k_kdec_a, k_batch_inv, "
                           "k_kdec_b); kernel_ms is that pass timed with HIP events on the launching stream; the per-kernel split is in "
                           "profiles/r04/"}
         line = {

@@ -534,9 +534,10 @@ __device__ __forceinline__ void rec_load(Fp28& x, const int4* src) {
 // FOUR Fp2 products per squaring.  k_ksq gives each to one lane (4 product blocks + 2 reductions per lane, four lanes per
 // check, SIXTEEN checks per wavefront, no idle lane), operands in registers, the products exchanged inside the lane quad
 // with DPP (no LDS traffic but the parked copy of a lane's own coefficient, no step tables).  An exponentiation by |x| is
-// ONE run of 63 squarings that stores a snapshot of (z2..z5) after 16, 48, 57, 60, 62 and 63 squarings (the set bits
-// of |x|); k_kdec_a / k_batch_inv / k_kdec_b recover z0, z1 of the six snapshots (one shared batched inversion), and the
-// step program multiplies them.  tools/coopgen.py emu_ksq / emu_kdec are the limb-exact models of these kernels.
+// ONE run of 57 squarings that stores a snapshot of (z2..z5) after 16, 48 and 57 squarings (the low set bits of |x|; the
+// plan says which - rounds 2-3 ran all 63 with six snapshots); k_kdec_a / k_batch_inv / k_kdec_b recover z0, z1 of the
+// snapshots (one shared batched inversion), and the step program squares on uncompressed through bits 60, 62, 63 and
+// multiplies the six powers.  tools/coopgen.py emu_ksq / emu_kdec are the limb-exact models of these kernels.
 constexpr int KS_CHECKS = 16;
 #ifndef ZKP_KSQ_ASM
 #define ZKP_KSQ_ASM ZKP_COOP_ASM   // a squaring of k_ksq behind its operand forms as ONE asm block (tools/coopasm.py generate_ksq): the Fp2 product
@@ -1931,7 +1932,7 @@ __global__ void __launch_bounds__(64, 2) k_g2_mul28(const uint64_t* base, size_t
 
 // out = in^-1 for `count` planes of per-check Fp elements: plane j of the input is state element elem_n + j, of the output
 // elem_ninv + j (n_checks values each, record stride nc).  The final exponentiation's single inversion is
-// (ST_N, ST_NINV, 1), the decompression of the six snapshots of an x-power chain (ST_KN, ST_KNINV, 6).  One lane inverts
+// (ST_N, ST_NINV, 1), the decompression of the snapshots of an x-power chain (ST_KN, ST_KNINV, 3).  One lane inverts
 // B of the count * n_checks values (i, i + L, i + 2L, ...; L lanes) with Montgomery's simultaneous inversion: exclusive
 // prefix products parked in the output records, ONE inversion (a^(p-2) in the reference, src/fp.rs:307-319) of the total,
 // then two multiplications per value on the way back.
