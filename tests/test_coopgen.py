@@ -38,6 +38,23 @@ def test_emulated_pairing_of_generators_matches_model():
     assert em.counts["mulacc_steps"] > 100 and 40 < ec.plan_stats["mulacc_steps"] < 80
 
 
+@pytest.mark.parametrize("split", [2, 6])
+def test_x_power_chain_split_points_give_the_same_gt(split, monkeypatch):
+    """the point where an x-power chain leaves the compressed squaring run for Granger-Scott steps (KSQ_SPLIT; 3 is what ships,
+    6 = rounds 2-3: all 63 squarings compressed, six snapshots) changes the plan, never the value"""
+    monkeypatch.setattr(cg, "KSQ_SPLIT", split)
+    plan = cg.prog_fexp_c(True)
+    runs = [st for st in plan if st[0] == cg.PLAN_KSQ]
+    nsq = cg.X_BITS[split - 1]
+    assert [st[3] for st in runs] == [nsq - 1] + [nsq] * 4 and all(bin(st[4]).count("1") == split for st in runs)
+    pairs = [(m.G1_GEN, m.G2_GEN)]
+    em = cg.Emu(lines=cg.model_lines(pairs)).run(cg.prog_miller(1, False).steps)
+    ea = cg.Emu(state=em.state).run(cg.prog_fexp_a(False).steps)
+    ea.state[cg.ST_NINV] = cg.mont(m.fp_inv(cg.from_mont(ea.state[cg.ST_N])))
+    ec = cg.run_plan(plan, ea.state)
+    assert ec.wire_out == m.f12_flat_ints(m.final_exponentiation(m.multi_miller_loop(pairs))) and ec.is_identity is False
+
+
 def test_emulated_wire_roundtrip_and_three_pair_check(model_vectors):
     H = lambda s: int(s, 16)
     c = model_vectors["pairing"]["multi3"]
