@@ -1502,6 +1502,23 @@ static int reduce_after_local(zkp_ctx* c, int rc_local, int* d_all_ok, hipStream
     }
     return and_allreduce(c, d_all_ok, s);
 }
+// ... and of the host-pointer flavours: the rank's local AND (0 when its own call failed) goes to the device, through the collective
+// and back; the rank's own status is what the call returns
+static int host_flag_allreduce(zkp_ctx* c, int rc_local, int local, int* all_ok) {
+    if (rc_local) local = 0;
+    const std::string first = c->err;
+    int rc = bind(c);
+    if (rc) return rc_local ? rc_local : rc;
+    HostCall drain(c);
+    HIPCHK(c, hipMemcpyAsync(c->d_flag + 1, &local, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if ((rc = and_allreduce(c, c->d_flag + 1, c->stream))) return rc_local ? rc_local : rc;
+    int all = 0;
+    HIPCHK(c, hipMemcpyAsync(&all, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *all_ok = all;
+    if (rc_local) c->err = first;
+    return rc_local;
+}
 int zkp_and_allreduce_dev(zkp_ctx* c, void* d_flag, void* stream) {
     if (!c || !d_flag) return ZKP_ERR_ARG;
     int rc = bind(c);
@@ -1526,17 +1543,7 @@ int zkp_pairing_check_batch_allreduce(zkp_ctx* c, const uint64_t* g1, const uint
     // its own block's size or status - a rank that failed locally still takes part (with flag 0) so that no peer hangs
     int local = 1;
     const int rc_local = zkp_pairing_check_batch(c, g1, g2, inf1, inf2, n_checks, k, ok, &local);
-    if (rc_local) local = 0;
-    int rc = bind(c);
-    if (rc) return rc;
-    HostCall drain(c);
-    HIPCHK(c, hipMemcpyAsync(c->d_flag + 1, &local, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    if ((rc = and_allreduce(c, c->d_flag + 1, c->stream))) return rc;
-    int all = 0;
-    HIPCHK(c, hipMemcpyAsync(&all, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    *all_ok = all;
-    return rc_local;
+    return host_flag_allreduce(c, rc_local, local, all_ok);
 }
 int zkp_points_check_batch_allreduce_dev(zkp_ctx* c, const void* b1, const void* b2, size_t n_checks, size_t k, void* st1, void* st2, void* ok,
                                          void* all_ok, void* stream) {
@@ -1551,17 +1558,7 @@ int zkp_points_check_batch_allreduce(zkp_ctx* c, const uint8_t* b1, const uint8_
     if (!c->comm) { c->err = "no communicator: call zkp_comm_init_rank first"; return ZKP_ERR_COMM; }
     int local = 1;
     const int rc_local = zkp_points_check_batch(c, b1, b2, n_checks, k, st1, st2, ok, &local);
-    if (rc_local) local = 0;     // a rank that failed locally still takes part, with flag 0: no peer hangs
-    int rc = bind(c);
-    if (rc) return rc;
-    HostCall drain(c);
-    HIPCHK(c, hipMemcpyAsync(c->d_flag + 1, &local, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    if ((rc = and_allreduce(c, c->d_flag + 1, c->stream))) return rc;
-    int all = 0;
-    HIPCHK(c, hipMemcpyAsync(&all, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    *all_ok = all;
-    return rc_local;
+    return host_flag_allreduce(c, rc_local, local, all_ok);
 }
 int zkp_pairing_product_check_allgather(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n,
                                         uint64_t* out_gt, int* is_one) {
