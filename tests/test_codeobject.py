@@ -34,7 +34,7 @@ def test_hot_kernels_keep_their_registers():
     k = _kernels()
     find = lambda part: [v for n, v in k.items() if part in n]
     coop = find("6k_coopILi")
-    assert len(coop) == 2 and all(v["vgpr"] <= 168 and v["spill"] == 0 and v["scratch"] == 0 for v in coop), coop      # three waves per SIMD
+    assert len(coop) == 3 and all(v["vgpr"] <= 168 and v["spill"] == 0 and v["scratch"] == 0 for v in coop), coop      # three waves per SIMD
     (ksq,) = find("5k_ksqE")
     assert ksq["vgpr"] <= 168 and ksq["spill"] == 0 and ksq["scratch"] == 0, ksq
     (prep,) = find("k_prep_linesILb1E")                                                                               # the fused paths' line steps

@@ -239,7 +239,7 @@ def test_program_encoding_is_consistent():
         b = mk()
         hdr, tbl = cg.encode(b)
         assert len(hdr) % 4 == 0 and hdr[-4] == cg.OP_END
-        assert b.peak <= cg.LDS_WIDE_SLOTS, (name, b.peak)     # write_inc asserts the matching constants limit
+        assert b.peak <= cg.LDS_DEEP_SLOTS, (name, b.peak)     # write_inc asserts the matching constants limit (lds_config)
         depth = 0
         for i in range(0, len(hdr), 4):
             op = hdr[i] & 0xFF

@@ -54,6 +54,9 @@ LDS_SLOTS = 24         # slots every program must fit: 16 wavefronts of 5 groups
 # ... or, for programs that reference at most LDS_WIDE_CONSTS constants, LDS_WIDE_SLOTS slots: the constants region
 # (64 B per constant per wavefront) shrinks by as much as the five groups' extra slots take - same 10,096 B per wavefront
 LDS_WIDE_SLOTS, LDS_WIDE_CONSTS = 30, 4
+# ... or "deep": 36 slots + the first 24 constants, 13,056 B per wavefront - twelve wavefronts (the register bound of three per SIMD) still
+# fit the 160 KB of a CU.  The hard part's programs: two Fp12 values + the companion sums / differences of one of them.
+LDS_DEEP_SLOTS, LDS_DEEP_CONSTS = 36, 24
 G = 12                 # lanes per group
 NSLOT = 64             # group-local slots are 0..NSLOT-1; constants are NSLOT..127
 CONST_BASE = 64
@@ -508,12 +511,15 @@ class Builder:
     def _slots(dst):
         return dst.slots if isinstance(dst, V12) else list(dst)
 
-    def fp12_mul(self, dst, a, b):
+    def fp12_mul(self, dst, a, b, sd_out=None):
+        """a b.  merge_terms groups the 144 monomials by a's coefficients, so every two-slot operand form is a sum / difference
+        inside ONE Fp2 coefficient of b: when b carries companions (b.sd) every form of the step is a stored value.
+        sd_out: companions of the result (may be b.sd's slots: operands are read before anything is stored)."""
         d = self._slots(dst)
         c0 = b6_add(b6_mul(a.fp6(0), b.fp6(0)), b6_mul_v(b6_mul(a.fp6(1), b.fp6(1))))
         c1 = b6_add(b6_mul(a.fp6(0), b.fp6(1)), b6_mul(a.fp6(1), b.fp6(0)))
-        self.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(flatten12(c0, c1))])
-        return V12(d)
+        self.mulacc([{"dst": d[i], "bil": bl} for i, bl in enumerate(flatten12(c0, c1))], subst=self._sd_subst(b), sd=sd_out)
+        return V12(d, sd=sd_out)
 
     def _sd_subst(self, a):
         """companion slots of a -> substitution table for its sum / difference forms"""
@@ -826,6 +832,7 @@ def sqr_run(b, v, n):
 X_BITS = [i for i in range(64) if (M.BLS_X >> i) & 1]       # 16, 48, 57, 60, 62, 63
 KSQ_NSQ = X_BITS[-1]                                         # squarings of one x-power run
 KSQ_MASK = sum(1 << (e - 1) for e in X_BITS)                 # snapshot after squaring number e (loop index e - 1)
+KSQ_COMPANIONS = int(os.environ.get("ZKP_GEN_KSQ_COMPANIONS", "1"))  # companions for the squarings / products behind a compressed run (36 slots)
 KSQ_TOP_CHAIN = int(os.environ.get("ZKP_GEN_KSQ_TOP_CHAIN", "1"))   # the bits above the compressed run by the 7 * 15 chain (0: binary method)
 KSQ_SPLIT = int(os.environ.get("ZKP_GEN_KSQ_SPLIT", "3"))    # set bits of |x| the compressed run covers (6: all of them - rounds 2-3)
 
@@ -860,11 +867,21 @@ def cyc_exp(b, a, park, half=False):
         # d = a^(2^57); the bits above it are d^105, and 105 = 7 * 15 = (2^3 - 1)(2^4 - 1): with the free inverse of the cyclotomic
         # subgroup (the conjugate) that is 7 squarings + 2 products, d^7 = d^8 conj(d), (d^7)^15 = (d^7)^16 conj(d^7), instead of
         # the 6 + 3 of the binary method - a product costs 2.6 Granger-Scott squarings on this machine
+        # With KSQ_COMPANIONS (36 slots: the "deep" LDS configuration) the running square and the running product carry their
+        # companion sums / differences: every operand form of the squarings and of the products is then a stored value.
         def pow2k_times_conj(x, k):
-            y = b.cyclotomic_sqr(b.alloc(12), x)
-            for _ in range(k - 1):
-                y = b.cyclotomic_sqr(y, y)
-            y = b.fp12_mul(y, y, x.conj())
+            if KSQ_COMPANIONS:
+                ysd = x.sd if x.sd else b.alloc(12)          # x's companions become y's (read as operands, then overwritten)
+                y = b.cyclotomic_sqr(b.alloc(12), x, sd_out=ysd)
+                x = V12(x.slots, x.signs)
+                for _ in range(k - 1):
+                    y = b.cyclotomic_sqr(y, y, sd_out=y.sd)
+                y = b.fp12_mul(y, x.conj(), y, sd_out=y.sd)
+            else:
+                y = b.cyclotomic_sqr(b.alloc(12), x)
+                for _ in range(k - 1):
+                    y = b.cyclotomic_sqr(y, y)
+                y = b.fp12_mul(y, y, x.conj())
             b.release(x.slots)
             return y
         r = pow2k_times_conj(pow2k_times_conj(r, 3), 4)
@@ -877,8 +894,11 @@ def cyc_exp(b, a, park, half=False):
         b.release(sq.slots)
     for k in range(n - 2, -1, -1):
         s = b.fill(snap(k))
-        r = b.fp12_mul(r, r, s)
+        r = b.fp12_mul(r, s, r, sd_out=r.sd) if r.sd else b.fp12_mul(r, r, s)
         b.release(s.slots)
+    if r.sd:
+        b.release(r.sd)
+        r = V12(r.slots, r.signs)
     return r.conj(), ha
 
 
@@ -1819,11 +1839,14 @@ for _i in range(len(fexp_c_segments())):
 
 
 def lds_config(peak, nconst):
-    """0: LDS_SLOTS slots + all constants; 1: LDS_WIDE_SLOTS slots + LDS_WIDE_CONSTS constants (same LDS bytes)"""
+    """0: LDS_SLOTS slots + all constants; 1: LDS_WIDE_SLOTS slots + LDS_WIDE_CONSTS constants (same LDS bytes);
+    2: LDS_DEEP_SLOTS slots + LDS_DEEP_CONSTS constants"""
     if peak <= LDS_SLOTS:
         return 0
-    assert peak <= LDS_WIDE_SLOTS and nconst <= LDS_WIDE_CONSTS, (peak, nconst)
-    return 1
+    if peak <= LDS_WIDE_SLOTS and nconst <= LDS_WIDE_CONSTS:
+        return 1
+    assert peak <= LDS_DEEP_SLOTS and nconst <= LDS_DEEP_CONSTS, (peak, nconst)
+    return 2
 
 
 def write_inc(path):
@@ -1831,6 +1854,7 @@ def write_inc(path):
              "#pragma once", "#include <stdint.h>",
              "#define ZKP_COOP_G %d" % G, "#define ZKP_COOP_NSLOT_MAX %d" % NSLOT, "#define ZKP_COOP_NSLOT %d" % LDS_SLOTS,
              "#define ZKP_COOP_NCONST %d" % N_CONST, "#define ZKP_COOP_WIDE_NSLOT %d" % LDS_WIDE_SLOTS, "#define ZKP_COOP_WIDE_NCONST %d" % LDS_WIDE_CONSTS,
+             "#define ZKP_COOP_DEEP_NSLOT %d" % LDS_DEEP_SLOTS, "#define ZKP_COOP_DEEP_NCONST %d" % LDS_DEEP_CONSTS,
              "#define ZKP_COOP_ST_SIZE %d" % ST_SIZE,
              "#define ZKP_COOP_ST_G %d" % ST_G, "#define ZKP_COOP_ST_N %d" % ST_N, "#define ZKP_COOP_ST_NINV %d" % ST_NINV,
              "#define ZKP_COOP_ST_SNAP %d" % ST_SNAP, "#define ZKP_COOP_ST_KN %d" % ST_KN, "#define ZKP_COOP_ST_KNINV %d" % ST_KNINV,
@@ -1865,7 +1889,7 @@ def write_inc(path):
         nconst = max(x for x in used if x >= CONST_BASE) - CONST_BASE + 1
         wide = lds_config(b.peak, nconst)
         meta.append((n, len(hdr), len(tbl), b.peak, nconst, wide))
-    lines.append("// wide: the program runs with ZKP_COOP_WIDE_NSLOT slots and ZKP_COOP_WIDE_NCONST constants instead of ZKP_COOP_NSLOT / ZKP_COOP_NCONST")
+    lines.append("// wide: 1 = the program runs with ZKP_COOP_WIDE_NSLOT slots and ZKP_COOP_WIDE_NCONST constants instead of ZKP_COOP_NSLOT / ZKP_COOP_NCONST, 2 = with ZKP_COOP_DEEP_NSLOT / ZKP_COOP_DEEP_NCONST")
     lines.append("struct ZkpProgDesc { const uint32_t* hdr; uint32_t n_hdr; const uint32_t* tbl; uint32_t n_tbl; uint32_t nslot; uint32_t nconst; uint32_t wide; };")
     lines.append("static const ZkpProgDesc ZKP_PROGS[ZKP_PROG_COUNT] = {")
     for n, nh, nt, peak, nconst, wide in meta:

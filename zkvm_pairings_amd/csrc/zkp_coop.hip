@@ -157,6 +157,8 @@ __device__ __forceinline__ void canon28(uint32_t* f, const int32_t* x) {
 
 __host__ __device__ constexpr int coop_group_stride(int S) { return S + ((4 - S % 8) + 8) % 8; }
 // (+ 16 bytes behind the image with three wavefronts: the identity flags of the check that straddles them)
+constexpr int coop_cfg_slots(uint32_t cfg) { return cfg == 2 ? ZKP_COOP_DEEP_NSLOT : cfg == 1 ? ZKP_COOP_WIDE_NSLOT : ZKP_COOP_NSLOT; }
+constexpr int coop_cfg_consts(uint32_t cfg) { return cfg == 2 ? ZKP_COOP_DEEP_NCONST : cfg == 1 ? ZKP_COOP_WIDE_NCONST : ZKP_COOP_NCONST; }
 constexpr size_t coop_lds_bytes(int S, int SC) { return (size_t)4 * (SC + GROUPS * coop_group_stride(S)) * 16 + (WGW > 1 ? 16 : 0); }
 #ifndef ZKP_COOP_KARATSUBA
 #define ZKP_COOP_KARATSUBA 1   // acc_mul_k: 147 multiply-adds per product block instead of 196 (zkp_fp28.hpp); measured on one box,
@@ -2195,7 +2197,7 @@ struct CoopDev {
 // bits << 12, y = subtract-A2 bits | subtract-B2 bits << 12.  Lane -> (group, lane in group) and the slot -> address map are
 // k_coop's (gbase, slot_off); lanes 60..63 compute on group 4's addresses and never store.
 static void coop_resolve_table(const ZkpProgDesc& p, std::vector<uint4>& rt) {
-    const int S = p.wide ? ZKP_COOP_WIDE_NSLOT : ZKP_COOP_NSLOT, SC = p.wide ? ZKP_COOP_WIDE_NCONST : ZKP_COOP_NCONST;
+    const int S = coop_cfg_slots(p.wide), SC = coop_cfg_consts(p.wide);
     const int SG = coop_group_stride(S);
     const size_t rows = p.n_tbl / LIG + 2;
     constexpr int RL = 64 * WGW;   // lanes per row
@@ -2344,25 +2346,26 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     a.n_checks = n_checks;
     a.nc = nc;
     a.k = k;
-    const bool wide = d->progs[prog].wide != 0;
-    if (d->progs[prog].nslot > (uint32_t)(wide ? ZKP_COOP_WIDE_NSLOT : ZKP_COOP_NSLOT) ||
-        d->progs[prog].nconst > (uint32_t)(wide ? ZKP_COOP_WIDE_NCONST : ZKP_COOP_NCONST))
+    const uint32_t cfg = d->progs[prog].wide;      // LDS configuration: 0 plain, 1 wide, 2 deep (tools/coopgen.py lds_config)
+    if (cfg > 2 || d->progs[prog].nslot > (uint32_t)coop_cfg_slots(cfg) || d->progs[prog].nconst > (uint32_t)coop_cfg_consts(cfg))
         return hipErrorInvalidValue;
-    a.S = wide ? ZKP_COOP_WIDE_NSLOT : ZKP_COOP_NSLOT;
+    a.S = coop_cfg_slots(cfg);
     a.nconst = d->progs[prog].nconst;
     a.st_off = st_off;
     a.chk_off = chk_off;
 
-    const size_t lds_plain = coop_lds_bytes(ZKP_COOP_NSLOT, ZKP_COOP_NCONST), lds_wide = coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST);
     static_assert(12 / WGW * coop_lds_bytes(ZKP_COOP_NSLOT, ZKP_COOP_NCONST) <= 160 * 1024 &&
-                      12 / WGW * coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST) <= 160 * 1024,
+                      12 / WGW * coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST) <= 160 * 1024 &&
+                      12 / WGW * coop_lds_bytes(ZKP_COOP_DEEP_NSLOT, ZKP_COOP_DEEP_NCONST) <= 160 * 1024,
                   "twelve wavefronts (three per SIMD, the register bound) must fit the 160 KB of LDS of a CU");
-    size_t lds_bytes = wide ? lds_wide : lds_plain;
+    size_t lds_bytes = coop_lds_bytes(coop_cfg_slots(cfg), coop_cfg_consts(cfg));
     // occupancy experiments only (the VALUE is cached, not the pointer getenv returned: a later setenv may move the environment)
     static const long lds_pad = getenv("ZKP_COOP_LDS_PAD") ? atol(getenv("ZKP_COOP_LDS_PAD")) : 0;
     if (lds_pad > 0) lds_bytes += (size_t)lds_pad;
     unsigned blocks = (n_checks + GROUPS - 1) / GROUPS;
-    if (wide)
+    if (cfg == 2)
+        hipLaunchKernelGGL((k_coop<ZKP_COOP_DEEP_NSLOT, ZKP_COOP_DEEP_NCONST>), dim3(blocks), dim3(64 * WGW), lds_bytes, s, a);
+    else if (cfg == 1)
         hipLaunchKernelGGL((k_coop<ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST>), dim3(blocks), dim3(64 * WGW), lds_bytes, s, a);
     else
         hipLaunchKernelGGL((k_coop<ZKP_COOP_NSLOT, ZKP_COOP_NCONST>), dim3(blocks), dim3(64 * WGW), lds_bytes, s, a);
