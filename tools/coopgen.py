@@ -904,7 +904,8 @@ def cyc_exp(b, a, park, half=False):
 
 def prog_fexp_c(to_wire=True):
     """second half: finish the inversion, easy part, hard part (x-chain), output Gt.  At most TWO Fp12
-    values are LDS-resident at any time (24 slots => 16 waves per CU); everything else is parked in the
+    values are LDS-resident at any time - plus, behind a compressed squaring run, the companion sums / differences of one of
+    them (36 slots: the "deep" LDS configuration, still twelve wavefronts per CU); everything else is parked in the
     per-check state buffer (a spill or fill moves 768 B per check).  Returns a PLAN (Builder.cut): the step program is
     cut at every x-power chain, whose 63 squarings run as one compressed squaring kernel (cyc_exp)."""
     b = Builder()
