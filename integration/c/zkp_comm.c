@@ -8,6 +8,7 @@
  * rank must see all_ok = 0 while the other ranks' own ok bytes stay 1.  Pass 3: the product check over the whole batch through
  * one all-gather of 576 B per rank (zkp_pairing_product_check_allgather) is the identity on every rank.
  * The GPU box has one GPU: the test suite runs it with nranks = 1 (a one-rank communicator); on a node, nranks = number of GPUs. */
+#define _DEFAULT_SOURCE 1 /* usleep, aligned_alloc under a strict -std= */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,11 +30,11 @@ static const uint64_t P[6] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x67
 #define CHECKS 4
 
 static void neg_y(uint64_t* dst, const uint64_t* y) {
-    unsigned __int128 borrow = 0;
+    uint64_t borrow = 0;      /* p - y, limb by limb (y < p) */
     for (int i = 0; i < 6; i++) {
-        unsigned __int128 d = (unsigned __int128)P[i] - y[i] - (uint64_t)borrow;
-        dst[i] = (uint64_t)d;
-        borrow = (d >> 64) & 1;
+        const uint64_t d = P[i] - y[i], e = d - borrow;
+        borrow = (uint64_t)(P[i] < y[i]) | (uint64_t)(d < borrow);
+        dst[i] = e;
     }
 }
 

@@ -7,6 +7,7 @@
  * call on 2-pair checks e(a P, Q) e(-a P, Q) == 1 with every 7th check spoiled, and the AND flags; the same batch from
  * page-locked memory (zkp_host_alloc / zkp_host_register) with both timings printed. */
 #define _POSIX_C_SOURCE 199309L
+#define _DEFAULT_SOURCE 1 /* usleep, aligned_alloc under a strict -std= */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,11 +28,11 @@ static const uint64_t P[6] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x67
                               0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
 
 static void fp_neg(uint64_t* out, const uint64_t* y) { /* p - y, y != 0 */
-    unsigned __int128 borrow = 0;
+    uint64_t borrow = 0;
     for (int i = 0; i < 6; i++) {
-        unsigned __int128 d = (unsigned __int128)P[i] - y[i] - (uint64_t)borrow;
-        out[i] = (uint64_t)d;
-        borrow = (d >> 64) & 1;
+        const uint64_t d = P[i] - y[i], e = d - borrow;
+        borrow = (uint64_t)(P[i] < y[i]) | (uint64_t)(d < borrow);
+        out[i] = e;
     }
 }
 

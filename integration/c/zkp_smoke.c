@@ -32,11 +32,11 @@ int main(void) {
     uint64_t g1s[24], g2s[48];
     memcpy(g1s, G1, sizeof G1);
     memcpy(g1s + 12, G1, sizeof G1);
-    unsigned __int128 borrow = 0;
+    uint64_t borrow = 0;
     for (int i = 0; i < 6; i++) {
-        unsigned __int128 d = (unsigned __int128)P[i] - G1[6 + i] - (uint64_t)borrow;
-        g1s[12 + 6 + i] = (uint64_t)d;
-        borrow = (d >> 64) & 1;
+        const uint64_t d = P[i] - G1[6 + i], e = d - borrow;
+        borrow = (uint64_t)(P[i] < G1[6 + i]) | (uint64_t)(d < borrow);
+        g1s[12 + 6 + i] = e;
     }
     memcpy(g2s, G2, sizeof G2);
     memcpy(g2s + 24, G2, sizeof G2);

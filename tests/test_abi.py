@@ -115,7 +115,7 @@ def test_plain_c_consumers_compile_and_link(tmp_path):
     libdir = os.path.join(ROOT, "zkvm_pairings_amd")
     for src in sorted(glob.glob(os.path.join(ROOT, "integration", "c", "*.c"))):
         exe = str(tmp_path / os.path.basename(src)[:-2])
-        subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", libdir, "-lzkp_pairings",
+        subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", libdir, "-lzkp_pairings",
                                "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
 
 
