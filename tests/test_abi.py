@@ -1,6 +1,5 @@
 """CPU gate for the boundary: the C-ABI library loads and exports every symbol include/zkp_pairings.h
 declares (no compute calls: there is no GPU here), and refuses to pretend when no device exists."""
-import ctypes
 import os
 import re
 

@@ -4,7 +4,6 @@ D2H from pageable numpy arrays; batches above ZKP_HOST_SLICE pairs are pipelined
 only - never as bench.py's value."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import zkvm_pairings_amd as z
 from zkvm_pairings_amd import synthetic
 eng = z.PairingEngine(0)
