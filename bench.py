@@ -6,10 +6,19 @@ One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).  The workload is
 2^17 per GPU on 8).  A step = one pass of the hot path over this rank's resident shard: fused Miller loop + final
 exponentiation -> Gt (bit-exact vs the CPU oracle on a sample) + the Gt==identity flags, then - when there is more
 than one rank - ONE all-reduce(MIN) of the per-rank AND flag over RCCL (the only collective the path has).  Inputs
-are generated on the GPU before the timed region and stay resident in HBM."""
+are generated on the GPU before the timed region and stay resident in HBM.
+
+Launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU), or plainly
+`python bench.py --gpus N ...`: without WORLD_SIZE in the environment the process becomes a launcher - BEFORE it imports torch or touches
+HIP - that starts exactly that torchrun command as a CHILD process on 127.0.0.1, relays rank 0's JSON line and returns the child's code.
+
+--collective torch (default): the step's all-reduce goes through torch.distributed (backend nccl = RCCL).
+--collective abi: the step is ONE call of zkp_pairing_gt_check_batch_allreduce_dev per rank - the library's own RCCL communicator
+(zkp_comm_init_rank, the id handed round through a gloo group), i.e. the path a Rust / C host takes is the one that is timed."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -68,6 +77,45 @@ def usable_cores():
     return n
 
 
+def launch_ranks(n_ranks, argv):
+    """the launcher half of `python bench.py --gpus N` (N > 1, no WORLD_SIZE): run the N ranks under torch.distributed.run as a child
+    process (never an exec: nothing here has touched the GPU, and nothing will), relay rank 0's JSON line to stdout - everything else
+    the ranks print goes to stderr - and return the child's exit code (3 if no line came back from a child that claimed success)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("bench.py: launching %d ranks: %s\n" % (n_ranks, " ".join(cmd)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        txt = out.strip()
+        is_line = False
+        if txt.startswith("{") and '"metric"' in txt:
+            try:
+                json.loads(txt)
+                is_line = True
+            except ValueError:
+                pass
+        if is_line:
+            line = txt
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks ended with code 0 but printed no result line\n")
+        rc = 3
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,13 +130,23 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-4 / config-5 / host-API legs (they run outside the timed region)")
     ap.add_argument("--bare", action="store_true", help="profiling runs: only warm-up + timed passes reach the GPU (no phase timing, clock "
                                                         "probe or oracle leg), so that a rocprofv3 counter run holds exactly those passes")
+    ap.add_argument("--collective", choices=("torch", "abi"), default=os.environ.get("ZKP_BENCH_COLLECTIVE", "torch"),
+                    help="torch: all-reduce(MIN) through torch.distributed (nccl = RCCL); abi: the step is zkp_pairing_gt_check_batch_allreduce_dev "
+                         "on the library's own RCCL communicator (what a Rust / C host runs)")
+    ap.add_argument("--rank-echo", action="store_true", help=argparse.SUPPRESS)   # launcher self-test: ranks report and exit before any GPU use
     args = ap.parse_args()
     if args.bare:
         args.no_cpu_baseline = True
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.rank_echo:
+        if rank == 0:
+            print(json.dumps({"metric": "rank-echo", "world": world, "gpus": args.gpus, "master": os.environ.get("MASTER_ADDR")}), flush=True)
+        sys.exit(0 if world == args.gpus else 2)
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d - launch one rank per GPU with `python -m torch.distributed.run "
                          "--nnodes=1 --nproc-per-node %d ... bench.py --gpus %d`\n" % (args.gpus, world, args.gpus, args.gpus))
@@ -106,12 +164,20 @@ def main():
     if shared_gpu:
         local_rank = 0
     backend = os.environ.get("ZKP_BENCH_BACKEND", "nccl")
+    abi_step = args.collective == "abi"
+    if abi_step:
+        if shared_gpu and world > 1:
+            sys.stderr.write("bench.py: --collective abi needs one GPU per rank (RCCL refuses two ranks on one device)\n")
+            sys.exit(2)
+        backend = "gloo"        # control plane only (id hand-round, barriers, the max over ranks): the data path's collective is the library's
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ctl = None                  # a gloo group beside torch's RCCL one: agreement about a stuck RCCL call must not itself go through RCCL
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+            ctl = dist.new_group(backend="gloo")
         else:
             dist.init_process_group(backend)
 
@@ -132,12 +198,28 @@ def main():
     flag = torch.empty(1, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    def step():
-        eng.pairing_gt_check(g1, g2, 1, out_gt, ok, flag)
-        zdist.and_reduce(flag)  # AND of {0,1} flags == MIN; the only collective on the path (nothing to do on one rank)
+    if abi_step:
+        # the library's own communicator: 128 id bytes from rank 0, handed round by the host's means (here: the gloo group)
+        uid0 = [z.PairingEngine.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid0, src=0)
+        eng.comm_init_rank(world, rank, uid0[0])
+
+        def step():
+            # ONE C-ABI call per rank: Gt + ok bytes of the rank's shard, then ncclAllReduce(count 1, int32, MIN) of the AND flag
+            eng.pairing_gt_check_allreduce(g1, g2, 1, out_gt, ok, flag)
+    else:
+        def step():
+            eng.pairing_gt_check(g1, g2, 1, out_gt, ok, flag)
+            zdist.and_reduce(flag)  # AND of {0,1} flags == MIN; the only collective on the path (nothing to do on one rank)
 
     ranks = 1
-    if world > 1:
+    if world > 1 and abi_step:
+        probe = torch.ones(1, dtype=torch.int32, device=dev)
+        eng.and_allreduce(probe)
+        torch.cuda.synchronize()
+        ranks = eng.comm_info()[0]
+    elif world > 1:
         # establish the communicator outside the timed region even when --warmup 0 is requested
         probe = torch.ones(1, dtype=torch.int32, device=dev)
         zdist.and_reduce(probe)
@@ -157,6 +239,11 @@ def main():
     dt_rank = time.perf_counter() - t0
     dt = zdist.max_over_ranks(dt_rank, dev)
     all_ok = int(flag.item())
+    # fingerprint of rank 0's Gt block (wrap-around sums on the GPU): two runs of the same build on the same inputs print the same two
+    # numbers whatever carried the collective
+    w64 = torch.arange(1, 73, dtype=torch.int64, device=dev) * 0x1E3779B97F4A7C15 | 1
+    gt_fp = [int(out_gt.sum().item()), int((out_gt * w64).sum().item())]
+    del w64
 
     # ---- diagnosis of an N > 1 line (outside the timed region, every rank): what each rank's kernels take on their own, what
     # the collective takes on its own, each rank's wall time of the timed steps - gathered to rank 0.  A bad scaling curve then
@@ -168,7 +255,10 @@ def main():
         dist.barrier()
         tcoll = time.perf_counter()
         for _ in range(8):
-            zdist.and_reduce(flag)
+            if abi_step:
+                eng.and_allreduce(flag)
+            else:
+                zdist.and_reduce(flag)
         torch.cuda.synchronize()
         coll_ms = (time.perf_counter() - tcoll) * 1e3 / 8
         mine = torch.tensor([own_kernel_ms, coll_ms, 1e3 * dt_rank / args.steps, float(n)], dtype=torch.float64)
@@ -179,11 +269,14 @@ def main():
     # an error here costs the line one field, never the measurement above
     abi_coll, abi_hung = None, False
     # (ZKP_BENCH_FORCE_ABI_PROBE=1: run the probe on a single rank too - a one-rank communicator; the GPU suite's rehearsal of this code)
-    if (world > 1 and backend == "nccl" and not shared_gpu) or (world == 1 and os.environ.get("ZKP_BENCH_FORCE_ABI_PROBE") == "1"):
+    if abi_step:
+        abi_coll = {"ok": True, "ranks_ok": ranks, "what": "--collective abi: the TIMED step is zkp_pairing_gt_check_batch_allreduce_dev on the library's "
+                                                           "communicator (%d ranks); no separate probe" % ranks}
+    elif (world > 1 and backend == "nccl" and not shared_gpu) or (world == 1 and os.environ.get("ZKP_BENCH_FORCE_ABI_PROBE") == "1"):
         import threading
         uid = [z.PairingEngine.comm_unique_id() if rank == 0 else None]
         if world > 1:
-            dist.broadcast_object_list(uid, src=0, device=dev)
+            dist.broadcast_object_list(uid, src=0, group=ctl)
         res = {}
 
         def abi_probe():
@@ -216,13 +309,13 @@ def main():
         # every rank leaves the same way: if any rank's probe is stuck, all skip the orderly shutdown below
         abi_coll["ranks_ok"] = (1 if abi_coll.get("ok") else 0) if world == 1 else None
         if world > 1:
-            hung_any = torch.tensor([1 if abi_hung else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(hung_any, op=dist.ReduceOp.MAX)
-            abi_hung = bool(hung_any.item())
-            if not abi_hung:
-                oks = torch.tensor([1 if abi_coll.get("ok") else 0], dtype=torch.int32, device=dev)
-                dist.all_reduce(oks, op=dist.ReduceOp.SUM)
-                abi_coll["ranks_ok"] = int(oks.item())
+            # over the gloo group: a rank whose probe is stuck inside RCCL must still be able to say so
+            both = torch.tensor([1 if abi_hung else 0, 1 if abi_coll.get("ok") else 0], dtype=torch.int32)
+            mx = both.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=ctl)
+            dist.all_reduce(both, op=dist.ReduceOp.SUM, group=ctl)
+            abi_hung = bool(mx[0].item())
+            abi_coll["ranks_ok"] = int(both[1].item())
         abi_coll["what"] = ("the path's one collective through the C ABI: zkp_comm_init_rank on %d ranks, 8 x zkp_and_allreduce_dev (mean ms), one "
                             "zkp_pairing_check_batch_allreduce_dev of 4096 pairs per rank; rank 0's view" % world)
 
@@ -425,8 +518,23 @@ def main():
                                        "sample": "first %d pairs of the sample" % n_slow_all}},
                    "sample": "%d of rank 0's %d pairs (every %d-th), CPU restatement oracle/, %d threads (the job's CPU share; the host "
                              "reports %d cores)" % (ns, n, n // ns, threads, host_cores)}
-        collective = ("1 all-reduce(MIN) of the AND flag over %d ranks (%s)" % (ranks, "RCCL" if backend == "nccl" else backend + ", shared-GPU rehearsal")) \
-            if ranks > 1 else "one rank: no collective"
+        if abi_step:
+            collective = "step = zkp_pairing_gt_check_batch_allreduce_dev: 1 ncclAllReduce(MIN) of the AND flag on the library's RCCL communicator, %d rank(s)" % ranks
+        else:
+            collective = ("1 all-reduce(MIN) of the AND flag over %d ranks (%s)" % (ranks, "RCCL through torch.distributed" if backend == "nccl" else backend + ", shared-GPU rehearsal")) \
+                if ranks > 1 else "one rank: no collective"
+        # what ONE GPU says about the strong-scaling curve: a rank's shard at N = 2 / 4 / 8 timed on this build, this box (HIP events, no
+        # collective) - the kernels' tails weigh more on a smaller grid, so N ranks cannot beat N x (shard rate / full rate)
+        scaling_bound = None
+        if world == 1 and not args.bare and not args.pairs_per_gpu and n >= (1 << 13):
+            scaling_bound = {"full": {"pairs": n, "ms": kern_ms}, "shards": []}
+            for parts in (2, 4, 8):
+                m = n // parts
+                ms_m = eng.time_pairing(g1[:m], g2[:m], out_gt[:m], 2)
+                scaling_bound["shards"].append({"n_gpus": parts, "pairs": m, "ms": ms_m, "rate_vs_full": (m / ms_m) / (n / kern_ms),
+                                                "max_speedup": parts * (m / ms_m) / (n / kern_ms)})
+            scaling_bound["what"] = ("measured in this run: one pass over the first 2^20/N pairs of the batch on this GPU against the full pass; "
+                                     "max_speedup is the ceiling of the N-GPU strong-scaling curve before collective and host cost anything")
         roof = {"bound": "valu-int (neither hbm nor mfma: 384-bit modular arithmetic; algorithmic intensity 6.56 M MAC per 864 B of I/O = 7,600 MAC/B, "
                          "executed intensity ~30 MAC/B with the line stream and the per-check state that pass through HBM - still 6x above the "
                          "4.9 MAC/B ridge of 39.3 T MAC/s over 8 TB/s)",
@@ -464,8 +572,9 @@ def main():
             "config": {"workload": "batch of %d random (G1,G2) pairs (BASELINE config 3) sharded over %d GPU(s): fused Miller loop + final "
                                    "exponentiation, Gt + identity flags out; %s" % (global_pairs, world, collective),
                        "pairs_per_gpu": n, "global_pairs": global_pairs, "ranks": ranks, "kernel_family": args.kernel,
-                       "shared_gpu_rehearsal": shared_gpu, "collective_backend": (backend if ranks > 1 else None),
-                       "all_ok_flag": all_ok, "gt_sample_bit_exact": parity},
+                       "shared_gpu_rehearsal": shared_gpu, "collective": args.collective,
+                       "collective_backend": ("rccl (library communicator, zkp_comm_init_rank)" if abi_step else (backend if ranks > 1 else None)),
+                       "all_ok_flag": all_ok, "gt_sample_bit_exact": parity, "gt_fingerprint_rank0": gt_fp},
             "roofline": roof,
             "cpu_baseline": cpu,
             "secondary_workloads": secondary,
@@ -476,12 +585,15 @@ def main():
                              for i, r in enumerate(rank_diag)],
                 "what": "kernel_ms_alone: one pass of the rank's shard timed with HIP events, no collective; collective_ms_alone: one "
                         "all-reduce(MIN) of the flag (mean of 8, after a barrier); step_wall_ms: the rank's own wall time per timed step",
-                "single_gpu_bound": "a shard of 2^20 / N pairs runs at 99 / 97 / 95.6 % of the 2^20-pair rate on one GPU (N = 2 / 4 / 8: the kernels' "
-                                    "tails weigh more on a smaller grid), so the curve cannot exceed 1.98x / 3.88x / 7.65x"},
+                "single_gpu_bound": "see strong_scaling_bound of the N = 1 line of the same build (a shard of 2^20 / N pairs timed on one GPU)"},
+            "strong_scaling_bound": scaling_bound,
         }
         print(json.dumps(line), flush=True)
     if abi_hung:
         os._exit(0 if (line is None or line["config"]["gt_sample_bit_exact"] is not False) else 3)   # a stuck RCCL thread must not hold the exit
+    if abi_step:
+        torch.cuda.synchronize()
+        eng.comm_destroy()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -280,6 +280,11 @@ int zkp_pairing_check_batch_allreduce(zkp_ctx* ctx, const uint64_t* g1, const ui
 /* d_all_ok (one int32, required) receives the AND over all ranks; asynchronous on `stream` */
 int zkp_pairing_check_batch_allreduce_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1, const void* d_inf2,
                                           size_t n_checks, size_t k, void* d_ok, void* d_all_ok, void* stream);
+/* pairing() + the Gt::identity() check of this rank's block (zkp_pairing_gt_check_batch_dev: Gt out, may be NULL, + ok bytes) and the
+ * same ONE all-reduce of the AND flag - BASELINE config 3 ("2^20 pairings sharded across 8 GPUs with RCCL AND-reduce of Gt==identity")
+ * as one call per rank; it is the step `bench.py --collective abi` times.  d_all_ok is required.  (ABI version 4) */
+int zkp_pairing_gt_check_batch_allreduce_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1, const void* d_inf2,
+                                             size_t n_checks, size_t k, void* d_out_gt, void* d_ok, void* d_all_ok, void* stream);
 /* BASELINE config 5 on a node ("subgroup check + pairing on raw points, 8 GPUs"): this rank's block of zkp_points_check_batch, then the
  * same ONE all-reduce of the AND flag; status and ok bytes stay per rank.  d_all_ok / all_ok are required. */
 int zkp_points_check_batch_allreduce(zkp_ctx* ctx, const uint8_t* g1_bytes, const uint8_t* g2_bytes, size_t n_checks, size_t k, uint8_t* st1,

@@ -1,11 +1,12 @@
 //! UNTESTED - the build image has no Rust toolchain; this crate has never been compiled.
 //!
-//! `zkp-pairings-sys`: raw bindings to include/zkp_pairings.h (ABI version 3) plus safe batch wrappers over slices of
+//! `zkp-pairings-sys`: raw bindings to include/zkp_pairings.h (ABI version 4) plus safe batch wrappers over slices of
 //! limbs.  Wire formats are the zkvm-pairings crate's own in-memory layouts: `Fp.0: [u64; 6]` canonical little-endian
 //! limbs (reference src/fp.rs:24), Fp12 in declaration order (src/fp12.rs:13-16), points as coordinate arrays plus a
 //! parallel infinity byte array.  The crate-level API (`pairing`, `multi_miller_loop`, `final_exponentiation`, `Gt`)
 //! over the crate's own types is `integration/rust/pairings.rs`, the file to drop into the crate's empty src/pairings.rs.
 use core::ffi::{c_char, c_int, c_uint, c_void};
+use core::ptr;
 
 #[repr(C)]
 pub struct ZkpCtx {
@@ -135,6 +136,9 @@ extern "C" {
     pub fn zkp_pairing_check_batch_allreduce_dev(ctx: *mut ZkpCtx, d_g1: *const c_void, d_g2: *const c_void, d_inf1: *const c_void,
                                                  d_inf2: *const c_void, n_checks: usize, k: usize, d_ok: *mut c_void,
                                                  d_all_ok: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn zkp_pairing_gt_check_batch_allreduce_dev(ctx: *mut ZkpCtx, d_g1: *const c_void, d_g2: *const c_void, d_inf1: *const c_void,
+                                                    d_inf2: *const c_void, n_checks: usize, k: usize, d_out_gt: *mut c_void,
+                                                    d_ok: *mut c_void, d_all_ok: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn zkp_points_check_batch_allreduce(ctx: *mut ZkpCtx, g1_bytes: *const u8, g2_bytes: *const u8, n_checks: usize, k: usize, st1: *mut u8,
                                             st2: *mut u8, ok: *mut u8, all_ok: *mut c_int) -> c_int;
     pub fn zkp_points_check_batch_allreduce_dev(ctx: *mut ZkpCtx, d_g1_bytes: *const c_void, d_g2_bytes: *const c_void, n_checks: usize,
@@ -361,12 +365,20 @@ impl Engine {
 
     /// This rank's contiguous block of a sharded check + the path's ONE collective (RCCL all-reduce(MIN) of the AND flag):
     /// returns (this rank's per-check flags, AND over ALL ranks' checks).  Every rank must call it once per global check.
+    ///
+    /// A LOCAL argument error (slice lengths, k) must not keep this rank out of the collective its peers are waiting in: the
+    /// wrappers below then enter it through the same entry point with arguments the library itself refuses (no points, one
+    /// check) - the rank takes part with flag 0 / the zero record, every rank reads `false` - and return the local error.
     pub fn pairing_check_batch_allreduce(&mut self, g1: &[u64], g2: &[u64], inf1: Option<&[u8]>, inf2: Option<&[u8]>, k: usize)
                                          -> Result<(Vec<u8>, bool), Error> {
-        let n = Self::pairs(g1, g2, inf1, inf2)?;
-        if k == 0 || n % k != 0 {
-            return Err(Error { status: ZKP_ERR_ARG, detail: "the number of pairs is not a multiple of k".into() });
-        }
+        let n = match Self::pairs(g1, g2, inf1, inf2) {
+            Ok(n) if k != 0 && n % k == 0 => n,
+            other => {
+                let mut all: c_int = 0;
+                unsafe { zkp_pairing_check_batch_allreduce(self.0, ptr::null(), ptr::null(), ptr::null(), ptr::null(), 1, 1, ptr::null_mut(), &mut all) };
+                return Err(other.err().unwrap_or(Error { status: ZKP_ERR_ARG, detail: "the number of pairs is not a multiple of k".into() }));
+            }
+        };
         let mut ok = vec![0u8; n / k];
         let mut all: c_int = 1;
         let rc = unsafe {
@@ -379,6 +391,8 @@ impl Engine {
     #[allow(clippy::type_complexity)]
     pub fn points_check_batch_allreduce(&mut self, g1_bytes: &[u8], g2_bytes: &[u8], k: usize) -> Result<(Vec<u8>, Vec<u8>, Vec<u8>, bool), Error> {
         if g1_bytes.len() % 96 != 0 || g2_bytes.len() != 2 * g1_bytes.len() || k == 0 || (g1_bytes.len() / 96) % k != 0 {
+            let mut all: c_int = 0;
+            unsafe { zkp_points_check_batch_allreduce(self.0, ptr::null(), ptr::null(), 1, 1, ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), &mut all) };
             return Err(Error { status: ZKP_ERR_ARG, detail: "byte string lengths / k".into() });
         }
         let n = g1_bytes.len() / 96;
@@ -393,9 +407,15 @@ impl Engine {
     /// ONE product check over the whole sharded batch: this rank's Miller product, one all-gather of 576 B per rank, one final
     /// exponentiation; every rank gets the same (Gt, is_one)
     pub fn pairing_product_check_allgather(&mut self, g1: &[u64], g2: &[u64], inf1: Option<&[u8]>, inf2: Option<&[u8]>) -> Result<([u64; 72], bool), Error> {
-        let n = Self::pairs(g1, g2, inf1, inf2)?;
         let mut gt = [0u64; 72];
         let mut one: c_int = 0;
+        let n = match Self::pairs(g1, g2, inf1, inf2) {
+            Ok(n) => n,
+            Err(e) => {
+                unsafe { zkp_pairing_product_check_allgather(self.0, ptr::null(), ptr::null(), ptr::null(), ptr::null(), 1, ptr::null_mut(), &mut one) };
+                return Err(e);
+            }
+        };
         let rc = unsafe { zkp_pairing_product_check_allgather(self.0, g1.as_ptr(), g2.as_ptr(), opt_ptr(inf1), opt_ptr(inf2), n, gt.as_mut_ptr(), &mut one) };
         if rc == ZKP_OK { Ok((gt, one != 0)) } else { Err(self.err(rc)) }
     }

@@ -24,7 +24,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), "libzkp_pairings.so does not export %s" % n
         assert n in _lib.SIGNATURES, "python binding table lacks %s" % n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.zkp_abi_version() == 3
+    assert lib.zkp_abi_version() == 4
 
 
 def test_rust_and_c_bindings_list_the_same_symbols():
@@ -162,3 +162,39 @@ def test_splitmix_vectorised_matches_model(model_vectors):
     assert s.shape == (5, 4) and all(0 < synthetic.scalar_to_int(r) < synthetic.R_ORDER for r in s)
     # offset continues the same stream
     assert np.array_equal(synthetic.scalars(synthetic.SEED, 5)[2:], synthetic.scalars(synthetic.SEED, 3, offset=2))
+
+
+def test_wrappers_enter_the_collective_before_raising_a_local_argument_error():
+    """a rank whose OWN arguments are wrong (sizes that do not match, k that does not divide n) must still enter the collective its
+    peers wait in - through the same entry point, with arguments the library refuses, so that it takes part with flag 0 / the zero
+    record - and raise afterwards.  Checked on a recording stand-in for the library: no GPU, no communicator needed."""
+    from zkvm_pairings_amd import PairingEngine
+
+    class Recorder:
+        def __init__(self):
+            self.calls = []
+
+        def __getattr__(self, name):
+            def fn(*a):
+                self.calls.append((name, a))
+                return -1
+            return fn
+
+    eng = object.__new__(PairingEngine)
+    eng._lib, eng._h, eng.device = Recorder(), None, 0
+    g1, g2 = np.zeros((4, 12), dtype=np.uint64), np.zeros((3, 24), dtype=np.uint64)
+    with pytest.raises(ValueError):
+        eng.pairing_check_allreduce(g1, g2, 1)
+    with pytest.raises(ValueError):
+        eng.pairing_check_allreduce(g1, np.zeros((4, 24), dtype=np.uint64), 3)          # k does not divide n
+    with pytest.raises(ValueError):
+        eng.points_check_allreduce(np.zeros((4, 96), dtype=np.uint8), np.zeros((3, 192), dtype=np.uint8), 1)
+    with pytest.raises(ValueError):
+        eng.pairing_product_check_allgather(g1, g2)
+    names = [c[0] for c in eng._lib.calls]
+    assert names == ["zkp_pairing_check_batch_allreduce", "zkp_pairing_check_batch_allreduce", "zkp_points_check_batch_allreduce",
+                     "zkp_pairing_product_check_allgather"]
+    # ... with no points and ONE check / pair: the library's own ZKP_ERR_ARG path, which joins with flag 0 / the zero record
+    for name, a in eng._lib.calls:
+        ints = [x for x in a if isinstance(x, int)]
+        assert ints[:1] == [1], (name, a)

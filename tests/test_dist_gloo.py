@@ -144,3 +144,22 @@ def test_shard_range_partitions():
             assert all(blocks[i][1] == blocks[i + 1][0] for i in range(ws - 1))
             sizes = [b - a for a, b in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """`python bench.py --gpus N` without torchrun around it (how the driver starts the N = 1 bench): the process becomes a launcher
+    before torch or HIP is touched, runs the N ranks under torch.distributed.run as a child on 127.0.0.1, relays rank 0's line alone
+    on stdout and returns the ranks' code.  --rank-echo makes the ranks report and leave before any GPU use, so this runs on CPU."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--rank-echo"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-1500:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "rank-echo", "world": 2, "gpus": 2, "master": "127.0.0.1"}
+    assert "torch.distributed.run" in out.stderr
+    # a WORLD_SIZE that contradicts --gpus is still refused (rc 2), and a failing rank's code comes back through the launcher
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--rank-echo"], capture_output=True, text=True, timeout=60, env=dict(env, WORLD_SIZE="3"))
+    assert out.returncode == 2

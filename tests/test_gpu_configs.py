@@ -372,9 +372,43 @@ def test_two_ranks_sharded_check_equals_single_rank(tmp_path):
     detail = line["ranks_detail"]["per_rank"]
     assert [d["rank"] for d in detail] == [0, 1] and all(d["pairs"] == 32768 and d["kernel_ms_alone"] > 0 and d["collective_ms_alone"] >= 0
                                                          and d["step_wall_ms"] > 0 for d in detail)
-    # and the guard: --gpus must match the number of ranks
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    # the same line from a PLAIN start (no torchrun around it): bench.py launches its two ranks itself, as a child process, before it
+    # touches torch or HIP, and relays rank 0's line and the ranks' exit code
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pairs", "65536",
+                            "--cpu-sample", "512"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                           env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert plain.returncode == 0, plain.stdout[-2000:] + plain.stderr[-2000:]
+    lines = [ln for ln in plain.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                        # ONE JSON line on stdout, everything else went to stderr
+    pl = json.loads(lines[0])
+    assert pl["n_gpus"] == 2 and pl["config"]["ranks"] == 2 and pl["config"]["gt_sample_bit_exact"] is True
+    assert pl["config"]["gt_fingerprint_rank0"] == line["config"]["gt_fingerprint_rank0"]
+    # and the guard that stays: a WORLD_SIZE that does not match --gpus
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, cwd=ROOT,
+                         env=dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"))
     assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
+
+
+def test_bench_step_through_the_abi_collective_equals_the_torch_one():
+    """`bench.py --collective abi`: the timed step is ONE zkp_pairing_gt_check_batch_allreduce_dev per rank on the library's own RCCL
+    communicator (one rank here: all one GPU allows).  Same inputs, same build: Gt fingerprint, flag and parity equal the torch line's."""
+    import json
+
+    def run(*extra):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs", "32768", "--cpu-sample", "256",
+                              "--no-secondary"] + list(extra), capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+    t, a = run(), run("--collective", "abi")
+    assert t["config"]["collective"] == "torch" and a["config"]["collective"] == "abi"
+    assert "zkp_pairing_gt_check_batch_allreduce_dev" in a["config"]["workload"] and a["abi_collective"]["ok"] is True
+    for key in ("gt_fingerprint_rank0", "all_ok_flag", "gt_sample_bit_exact", "pairs_per_gpu", "ranks"):
+        assert t["config"][key] == a["config"][key], key
+    assert a["config"]["gt_sample_bit_exact"] is True and a["value"] > 0
+    # the N = 1 line measures the ceiling of the strong-scaling curve instead of quoting it
+    sb = t["strong_scaling_bound"]
+    assert [x["n_gpus"] for x in sb["shards"]] == [2, 4, 8] and all(0.5 < x["rate_vs_full"] < 1.3 for x in sb["shards"])
 
 
 def test_rccl_all_reduce_min_on_one_rank():

@@ -306,3 +306,91 @@ def test_line_stores_obey_the_lane_mask():
     stored = sorted({(a - 0x300000) // (nc * 64) for a in emu.mem})
     assert stored == [0, 2, 4], stored                 # records e + 0 of lane 0; nothing of lane 1 (records 1, 3, 5)
     assert emu.exec == 3
+
+
+def _exec_discipline(path):
+    """every write to EXEC inside a generated asm block takes its value from (a) the SGPR pair that saved EXEC at the block's entry,
+    (b) a lane-role mask that was ANDed with that pair, (c) an operand the CALLER computed under its own EXEC (%[smask], a ballot;
+    %[exec...]), or (d) vcc / another pair ANDed with (a).  Returns the number of EXEC writes checked."""
+    import re
+    inside, checked = set(), 0
+    for raw in open(path):
+        m = re.match(r'\s*"(.*?)\\n', raw)
+        if raw.startswith("#define"):
+            inside = set()                                   # a new block: nothing is known about EXEC yet
+        if not m:
+            continue
+        ins = m.group(1).strip()
+        mm = re.fullmatch(r"s_mov_b64 (s\[\d+:\d+\]), exec", ins)
+        if mm:
+            inside.add(mm.group(1))
+            continue
+        mm = re.fullmatch(r"s_and_b64 (s\[\d+:\d+\]|exec|vcc), (\S+), (\S+)", ins)
+        if mm:
+            dst, a, b = mm.groups()
+            a = a.rstrip(",")
+            ok = a in inside or b in inside or a == "exec" or b == "exec"
+            if dst == "exec":
+                assert ok, (path, ins)
+                checked += 1
+            elif ok and dst != "vcc":
+                inside.add(dst)
+            elif dst in inside:
+                inside.discard(dst)
+            continue
+        mm = re.fullmatch(r"s_mov_b64 exec, (\S+)", ins)
+        if mm:
+            src = mm.group(1)
+            assert src in inside or src.startswith("%["), "%s: `%s` loads EXEC with a mask that was never ANDed with the entry EXEC" % (path, ins)
+            checked += 1
+            continue
+        assert not re.match(r"s_\w+ exec\b", ins), (path, ins)     # no other way into EXEC
+        mm = re.match(r"s_\w+ (s\[\d+:\d+\]),", ins)
+        if mm and mm.group(1) in inside:
+            inside.discard(mm.group(1))                      # a pair that is overwritten by something else is no longer a mask
+    return checked
+
+
+def test_no_generated_block_loads_exec_with_an_absolute_mask():
+    """the lane-role masks of every asm block stay INSIDE the EXEC the block was entered with - checked on the checked-in includes,
+    i.e. on the text the compiler sees (the callers keep all 64 lanes alive today; nothing may depend on that)"""
+    csrc = os.path.join(ROOT, "zkvm_pairings_amd", "csrc")
+    n = sum(_exec_discipline(os.path.join(csrc, f)) for f in ("zkp_prep_dbl.inc", "zkp_valid_steps.inc", "zkp_coop_mulacc.inc"))
+    assert n > 200
+
+
+def test_doubling_step_on_half_a_wavefront_leaves_the_other_half_alone():
+    """the same block on four lanes with the second pair switched off at entry: its registers are never written, its records never
+    stored, the first pair's results are what the two-lane run gives, and EXEC comes back as it was"""
+    rng = random.Random(5)
+    g = prepasm.generate()
+    X, Y, W = [(rng.randrange(P), rng.randrange(P)) for _ in range(3)]
+    pts = [rng.randrange(P), rng.randrange(P)]
+
+    def run(lanes, entry):
+        emu = asmemu.Emu(lanes=lanes, subst=_subst())
+        emu.exec = entry
+        for c in range(2):
+            for base, val in ((g.X, X), (g.Y, Y), (g.W, W)):
+                for i, x in enumerate(cg.mont(val[c])):
+                    emu.v.setdefault(base + i, [None] * lanes)[c] = x & asmemu.M32
+        nc = 5
+        emu.s[110] = 2 * nc * 64
+        emu.s[112], emu.s[113] = entry, 0                   # the caller's ballot: a subset of its EXEC
+        emu.s[114], emu.s[115] = 0x200000, 0
+        emu.v[1] = [0, nc * 64] + [None] * (lanes - 2)
+        for v in (0, 1):
+            l = cg.mont(pts[v])
+            for lane in range(2):
+                for i in range(16):
+                    emu.lds[(v * 4 + i // 4) * 1024 + 16 * lane + 4 * (i % 4)] = (l[i] if i < NL else 0) & asmemu.M32
+        emu.run(g.lines)
+        return emu
+
+    two, four = run(2, 3), run(4, 3)
+    assert four.exec == 3
+    for r, vals in four.v.items():
+        assert vals[2] is None and vals[3] is None, "v%d of a lane the caller had switched off was written" % r
+        if r in two.v:
+            assert vals[:2] == two.v[r][:2], r
+    assert four.mem == two.mem and len(two.mem) > 0

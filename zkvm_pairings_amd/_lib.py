@@ -68,6 +68,7 @@ SIGNATURES = {
     "zkp_and_allreduce_dev": (c_int, [c_vp, c_vp, c_vp]),
     "zkp_pairing_check_batch_allreduce": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, ctypes.POINTER(c_int)]),
     "zkp_pairing_check_batch_allreduce_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, c_vp, c_vp]),
+    "zkp_pairing_gt_check_batch_allreduce_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, c_vp, c_vp, c_vp]),
     "zkp_points_check_batch_allreduce": (c_int, [c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, c_vp, c_vp, ctypes.POINTER(c_int)]),
     "zkp_points_check_batch_allreduce_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "zkp_pairing_product_check_allgather": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, ctypes.POINTER(c_int)]),

@@ -2738,9 +2738,18 @@ hipError_t coop_g2_valid(CoopState* st, const uint64_t* g2, const uint8_t* inf, 
         if (two_waves) {
             hipLaunchKernelGGL(k_g2_valid_fast, dim3(blocks), dim3(64), 2 * 4 * 64 * sizeof(int4), s, g2, inf, (uint32_t)n, status);
         } else {
+            // at most 2^22 points per launch: the kernel addresses its scratch with 32-bit lane offsets and plane strides (2 lanes x 16 B
+            // x 8 planes per point wrap at 2^27 points), and the scratch stays at 1 GiB whatever the batch (launches on one stream
+            // run one after the other, so they may share it)
+            const size_t CH = (size_t)1 << 22;
             CoopDev* d = (CoopDev*)st->d_prog;
-            if ((e = ensure_buf(&d->vscratch, &d->vscratch_bytes, (size_t)blocks * 64 * 8 * sizeof(int4))) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_g2_valid_fast3, dim3(blocks), dim3(64), 3 * 4 * 64 * sizeof(int4), s, g2, inf, (uint32_t)n, status, d->vscratch);
+            const size_t big = n < CH ? n : CH;
+            if ((e = ensure_buf(&d->vscratch, &d->vscratch_bytes, ((2 * big + 63) / 64) * 64 * 8 * sizeof(int4))) != hipSuccess) return e;
+            for (size_t lo = 0; lo < n; lo += CH) {
+                const size_t m = n - lo < CH ? n - lo : CH;
+                hipLaunchKernelGGL(k_g2_valid_fast3, dim3((unsigned)((2 * m + 63) / 64)), dim3(64), 3 * 4 * 64 * sizeof(int4), s, g2 + 24 * lo,
+                                   inf ? inf + lo : nullptr, (uint32_t)m, status + lo, d->vscratch);
+            }
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;

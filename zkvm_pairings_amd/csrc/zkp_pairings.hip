@@ -423,6 +423,9 @@ struct zkp_ctx {
     // one-rank-per-GPU communicator (zkp_comm_init_rank); null until then
     ncclComm_t comm = nullptr;
     int comm_nranks = 0, comm_rank = 0;
+    // (nranks + 3) Fp12 records owned by the communicator: [0] this rank's record, [1..R] the gathered ones, [R+1] their product, [R+2] Gt.
+    // Allocated by zkp_comm_init_rank, so that no allocation stands between a rank and the all-gather its peers wait in.
+    uint64_t* comm_buf = nullptr;
 };
 
 namespace {
@@ -727,7 +730,7 @@ struct HostCall {
 // =============================================================================== C ABI
 extern "C" {
 
-int zkp_abi_version(void) { return 3; }
+int zkp_abi_version(void) { return 4; }
 
 const char* zkp_strerror(int status) {
     switch (status) {
@@ -780,6 +783,7 @@ void zkp_free(zkp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm_buf) { (void)hipFree(c->comm_buf); c->comm_buf = nullptr; }
     zkp::coop_free(&c->coop);
     for (int i = 0; i < 8; i++)
         if (c->buf[i]) (void)hipFree(c->buf[i]);
@@ -1462,7 +1466,16 @@ int zkp_comm_init_rank(zkp_ctx* c, int nranks, int rank, const void* unique_id) 
     if (rc) return rc;
     ncclUniqueId id;
     memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
-    NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    // the records of the all-gather variant first: a rank that cannot allocate them must fail HERE, before it becomes a peer
+    HIPCHK(c, hipMalloc((void**)&c->comm_buf, ((size_t)nranks + 3) * 576));
+    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        (void)hipFree(c->comm_buf);
+        c->comm_buf = nullptr;
+        c->comm = nullptr;
+        c->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r);
+        return ZKP_ERR_COMM;
+    }
     c->comm_nranks = nranks;
     c->comm_rank = rank;
     return ZKP_OK;
@@ -1476,6 +1489,7 @@ int zkp_comm_destroy(zkp_ctx* c) {
     ncclComm_t comm = c->comm;
     c->comm = nullptr;
     c->comm_nranks = c->comm_rank = 0;
+    if (c->comm_buf) { (void)hipFree(c->comm_buf); c->comm_buf = nullptr; }
     NCCLCHK(c, ncclCommDestroy(comm));
     return ZKP_OK;
 }
@@ -1510,7 +1524,13 @@ static int host_flag_allreduce(zkp_ctx* c, int rc_local, int local, int* all_ok)
     int rc = bind(c);
     if (rc) return rc_local ? rc_local : rc;
     HostCall drain(c);
-    HIPCHK(c, hipMemcpyAsync(c->d_flag + 1, &local, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    // the flag reaches the device by a kernel argument, not by a copy that could fail before the collective: whatever happened locally,
+    // this rank enters the all-reduce its peers are waiting in
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, c->d_flag + 1, local ? 1 : 0);
+    if (hipGetLastError() != hipSuccess && hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream) != hipSuccess) {
+        if (!rc_local) { c->err = "the AND flag could not be written to the device"; return ZKP_ERR_HIP; }
+        return rc_local;      // nothing left to join with
+    }
     if ((rc = and_allreduce(c, c->d_flag + 1, c->stream))) return rc_local ? rc_local : rc;
     int all = 0;
     HIPCHK(c, hipMemcpyAsync(&all, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1532,6 +1552,13 @@ int zkp_pairing_check_batch_allreduce_dev(zkp_ctx* c, const void* g1, const void
     // a rank with an empty block still sets its flag to 1; a rank whose own block FAILED still takes part, with flag 0, so that no
     // peer hangs in the collective (every rank then reads 0; this rank returns its own error)
     const int rc_local = zkp_pairing_check_batch_dev(c, g1, g2, i1, i2, n_checks, k, ok, all_ok, stream);
+    return reduce_after_local(c, rc_local, (int*)all_ok, S(stream));
+}
+int zkp_pairing_gt_check_batch_allreduce_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n_checks, size_t k,
+                                             void* out_gt, void* ok, void* all_ok, void* stream) {
+    if (!c || !all_ok) return ZKP_ERR_ARG;
+    if (!c->comm) { c->err = "no communicator: call zkp_comm_init_rank first"; return ZKP_ERR_COMM; }
+    const int rc_local = zkp_pairing_gt_check_batch_dev(c, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok, stream);
     return reduce_after_local(c, rc_local, (int*)all_ok, S(stream));
 }
 int zkp_pairing_check_batch_allreduce(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks,
@@ -1570,26 +1597,30 @@ int zkp_pairing_product_check_allgather(zkp_ctx* c, const uint64_t* g1, const ui
     if (rc) return rc;
     HostCall drain(c);
     const size_t R = (size_t)c->comm_nranks;
-    // this rank's Miller product -> c->prod[0..72) (the identity for an empty block), gathered into slot 5 (R records).  A rank whose
-    // own part fails still joins the collective - with the ZERO record, so that the product is 0 and every rank reads is_one = 0 (no
-    // peer hangs, none passes a check this rank's pairs never entered) - and returns its own error afterwards.
+    // this rank's Miller product -> the communicator's record 0 (the identity for an empty block), gathered into records 1..R.  A rank
+    // whose own part fails - bad arguments, staging, an allocation that runs out of memory, a launch error - still joins the collective,
+    // with the ZERO record, so that the product is 0 and every rank reads is_one = 0 (no peer hangs, none passes a check this rank's
+    // pairs never entered), and returns its own error afterwards.  The records the collective itself needs belong to the communicator
+    // (zkp_comm_init_rank allocated them): nothing that can fail stands between this point and ncclAllGather.
+    uint64_t* const mine = c->comm_buf;
+    uint64_t* const gathered = c->comm_buf + 72;
+    uint64_t* const total = c->comm_buf + 72 * (R + 1);
+    uint64_t* const gt = c->comm_buf + 72 * (R + 2);
     Staged st = {nullptr, nullptr, nullptr, nullptr};
-    if ((rc = ensure_prod(c, (n / 8 + 1 > R ? n / 8 + 1 : R))) || (rc = ensure(c, 5, R * 576)) || (rc = ensure(c, 4, 576))) return rc;
     int rc_local = bad_args ? ZKP_ERR_ARG : ZKP_OK;
     if (!rc_local && n) rc_local = stage_pairs(c, g1, g2, inf1, inf2, n, &st);
-    if (!rc_local) rc_local = miller_product_dev(c, st.g1, st.g2, st.i1, st.i2, n, n ? nullptr : c->prod, c->stream);
+    if (!rc_local) rc_local = miller_product_dev(c, st.g1, st.g2, st.i1, st.i2, n, mine, c->stream);
     const std::string first = c->err;
     if (rc_local) {
-        if (bind(c) != ZKP_OK || hipMemsetAsync(c->prod, 0, 576, c->stream) != hipSuccess) return rc_local;
+        if (bind(c) != ZKP_OK || hipMemsetAsync(mine, 0, 576, c->stream) != hipSuccess) return rc_local;
     }
-    NCCLCHK(c, ncclAllGather(c->prod, c->buf[5], 72, ncclUint64, c->comm, c->stream));
-    uint64_t* const total = c->prod + 72 * R;      // a spare record (ensure_prod keeps two behind the R the tree works on)
-    if ((rc = fp12_product_dev(c, (const uint64_t*)c->buf[5], R, total, c->stream))) return rc;
-    if ((rc = final_exp_dev(c, total, 1, (uint64_t*)c->buf[4], c->stream))) return rc;
-    hipLaunchKernelGGL(k_gt_is_one, dim3(1), dim3(64), 0, c->stream, (const uint64_t*)c->buf[4], c->d_flag);
+    NCCLCHK(c, ncclAllGather(mine, gathered, 72, ncclUint64, c->comm, c->stream));
+    if ((rc = fp12_product_dev(c, gathered, R, total, c->stream))) return rc_local ? rc_local : rc;
+    if ((rc = final_exp_dev(c, total, 1, gt, c->stream))) return rc_local ? rc_local : rc;
+    hipLaunchKernelGGL(k_gt_is_one, dim3(1), dim3(64), 0, c->stream, (const uint64_t*)gt, c->d_flag);
     HIPCHK(c, hipGetLastError());
     int one = 0;
-    if (out_gt) HIPCHK(c, hipMemcpyAsync(out_gt, c->buf[4], 576, hipMemcpyDeviceToHost, c->stream));
+    if (out_gt) HIPCHK(c, hipMemcpyAsync(out_gt, gt, 576, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&one, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (is_one) *is_one = one;

@@ -95,18 +95,22 @@ def gather_parts(part):
     return part.reshape(1, 72)
 
 
-def sharded_product_check(miller_product_fn, finish_fn, n_pairs):
+def sharded_product_check(miller_product_fn, finish_fn, n_pairs, device=None, dtype=torch.int64):
     """prod_{i < n_pairs} e(P_i, Q_i) == Gt::identity() over ranks.
     miller_product_fn(lo, hi) -> (72,) tensor: Miller product of pairs [lo, hi) (engine.miller_product; the
     empty range gives Fp12::one()); finish_fn(parts (world,72)) -> bool: final_exponentiation(prod parts) ==
-    identity (engine.fp12_product + engine.final_exponentiation).  Every rank returns the same bool."""
+    identity (engine.fp12_product + engine.final_exponentiation).  Every rank returns the same bool.
+    device / dtype: where and as what miller_product_fn returns its value ON EVERY RANK (default: the current CUDA device under
+    RCCL, the host under gloo; int64) - the record a failing rank contributes must match its peers' in both, or the all-gather
+    meant to keep them from hanging is itself mismatched."""
     rank, ws = world()
     lo, hi = shard_range(n_pairs, rank, ws)
     try:
         part = miller_product_fn(lo, hi)
     except Exception:
         # as above: the failing rank contributes the ZERO record (product 0, never the identity: every rank reads False) and raises
-        dev = "cpu" if not _active() or _host_backend() else torch.device("cuda", torch.cuda.current_device())
-        gather_parts(torch.zeros(72, dtype=torch.int64, device=dev))
+        if device is None:
+            device = "cpu" if not _active() or _host_backend() else torch.device("cuda", torch.cuda.current_device())
+        gather_parts(torch.zeros(72, dtype=dtype, device=device))
         raise
     return bool(finish_fn(gather_parts(part)))

@@ -363,6 +363,23 @@ class PairingEngine:
         self._chk(self._lib.zkp_comm_info(self._h, ctypes.byref(n), ctypes.byref(r)))
         return n.value, r.value
 
+    def _join_failed(self, entry, dev_flag=None):
+        """a LOCAL argument error found on this side of the ABI (sizes that do not match, k that does not divide n) must not keep the
+        rank out of the collective its peers are already waiting in: enter it through the same entry point with arguments the library
+        itself refuses (no points, one check) - it then takes part with flag 0 / the zero record - and let the caller raise afterwards"""
+        null = ctypes.c_void_p(None)
+        out = ctypes.c_int(0)
+        if entry == "check":
+            self._lib.zkp_pairing_check_batch_allreduce(self._h, null, null, null, null, 1, 1, null, ctypes.byref(out))
+        elif entry == "check_dev":
+            self._lib.zkp_pairing_check_batch_allreduce_dev(self._h, null, null, null, null, 1, 1, null, self._tp(dev_flag), self._stream())
+        elif entry == "gt_check_dev":
+            self._lib.zkp_pairing_gt_check_batch_allreduce_dev(self._h, null, null, null, null, 1, 1, null, null, self._tp(dev_flag), self._stream())
+        elif entry == "points":
+            self._lib.zkp_points_check_batch_allreduce(self._h, null, null, 1, 1, null, null, null, ctypes.byref(out))
+        else:
+            self._lib.zkp_pairing_product_check_allgather(self._h, null, null, null, null, 1, null, ctypes.byref(out))
+
     def and_allreduce(self, flag):
         """in-place AND (all-reduce MIN) of an int32[1] tensor of {0,1} over the communicator's ranks, on the current stream"""
         import torch
@@ -374,40 +391,72 @@ class PairingEngine:
         -> (ok bytes of this rank's checks, all_ok over ALL ranks: bool for host arrays, int32[1] tensor for device tensors)"""
         if _is_torch(g1):
             import torch
-            n = self._t_pairs(g1, g2, inf1, inf2, k)
+            allok = torch.empty(1, dtype=torch.int32, device=torch.device("cuda", self.device))
+            try:
+                n = self._t_pairs(g1, g2, inf1, inf2, k)
+            except (TypeError, ValueError):
+                self._join_failed("check_dev", allok)
+                raise
             ok = torch.empty(n // k, dtype=torch.uint8, device=g1.device)
-            allok = torch.empty(1, dtype=torch.int32, device=g1.device)
             self._chk(self._lib.zkp_pairing_check_batch_allreduce_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), n // k, k,
                                                                       self._tp(ok), self._tp(allok), self._stream()))
             return ok, allok
-        g1, g2 = _np(g1, 12), _np(g2, 24)
-        n = g1.shape[0]
-        if g2.shape[0] != n or k <= 0 or n % k:
-            raise ValueError("g1 / g2 sizes do not match or are not a multiple of k")
-        i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
+        try:
+            g1, g2 = _np(g1, 12), _np(g2, 24)
+            n = g1.shape[0]
+            if g2.shape[0] != n or k <= 0 or n % k:
+                raise ValueError("g1 / g2 sizes do not match or are not a multiple of k")
+            i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
+        except (TypeError, ValueError):
+            self._join_failed("check")
+            raise
         ok = np.empty(n // k, dtype=np.uint8)
         allok = ctypes.c_int(1)
         self._chk(self._lib.zkp_pairing_check_batch_allreduce(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n // k, k, _ptr(ok), ctypes.byref(allok)))
         return ok, bool(allok.value)
 
+    def pairing_gt_check_allreduce(self, g1, g2, k, out_gt, ok, all_ok, inf1=None, inf2=None):
+        """device tensors only: pairing_gt_check of this rank's block + the AND over all ranks in all_ok (int32[1], required) -
+        zkp_pairing_gt_check_batch_allreduce_dev, BASELINE config 3 as one call per rank"""
+        import torch
+        self._t_check(all_ok, None, "all_ok", rows=1, dtypes=(torch.int32,))
+        try:
+            n = self._t_pairs(g1, g2, inf1, inf2, k)
+            if out_gt is not None:
+                self._t_check(out_gt, 72, "out_gt", rows=n // k)
+            self._t_bytes(ok, n // k, "ok")
+        except (TypeError, ValueError):
+            self._join_failed("gt_check_dev", all_ok)
+            raise
+        self._chk(self._lib.zkp_pairing_gt_check_batch_allreduce_dev(self._h, self._tp(g1), self._tp(g2), self._tp(inf1), self._tp(inf2), n // k, k,
+                                                                     self._tp(out_gt), self._tp(ok), self._tp(all_ok), self._stream()))
+
     def points_check_allreduce(self, g1_bytes, g2_bytes, k):
         """config 5 on a node: this rank's block of points_check + the AND over all ranks (host arrays) -> (st1, st2, ok, all_ok)"""
-        b1 = np.ascontiguousarray(g1_bytes, dtype=np.uint8).reshape(-1, 96)
-        b2 = np.ascontiguousarray(g2_bytes, dtype=np.uint8).reshape(-1, 192)
-        n = b1.shape[0]
-        if b2.shape[0] != n or k <= 0 or n % k:
-            raise ValueError("byte strings / k do not match")
+        try:
+            b1 = np.ascontiguousarray(g1_bytes, dtype=np.uint8).reshape(-1, 96)
+            b2 = np.ascontiguousarray(g2_bytes, dtype=np.uint8).reshape(-1, 192)
+            n = b1.shape[0]
+            if b2.shape[0] != n or k <= 0 or n % k:
+                raise ValueError("byte strings / k do not match")
+        except (TypeError, ValueError):
+            self._join_failed("points")
+            raise
         s1, s2, okb = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8), np.empty(n // k, dtype=np.uint8)
         allok = ctypes.c_int(1)
         self._chk(self._lib.zkp_points_check_batch_allreduce(self._h, _ptr(b1), _ptr(b2), n // k, k, _ptr(s1), _ptr(s2), _ptr(okb), ctypes.byref(allok)))
         return s1, s2, okb, bool(allok.value)
 
     def pairing_product_check_allgather(self, g1, g2, inf1=None, inf2=None):
-        g1, g2 = _np(g1, 12), _np(g2, 24)
-        n = g1.shape[0]
-        if g2.shape[0] != n:
-            raise ValueError("g1 and g2 hold different numbers of points")
-        i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
+        try:
+            g1, g2 = _np(g1, 12), _np(g2, 24)
+            n = g1.shape[0]
+            if g2.shape[0] != n:
+                raise ValueError("g1 and g2 hold different numbers of points")
+            i1, i2 = _flags(inf1, n, "inf1"), _flags(inf2, n, "inf2")
+        except (TypeError, ValueError):
+            self._join_failed("product")
+            raise
         gt = np.empty(72, dtype=np.uint64)
         one = ctypes.c_int(0)
         self._chk(self._lib.zkp_pairing_product_check_allgather(self._h, _ptr(g1), _ptr(g2), _ptr(i1), _ptr(i2), n, _ptr(gt), ctypes.byref(one)))
