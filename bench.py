@@ -370,11 +370,31 @@ def main():
                                   "kernels are estimates from their source"}
         except Exception as ex:      # the counter needs tools/ and tests/golden/ of the repository
             executed = {"total": None, "error": repr(ex)}
+        # per kernel class: one pass with every launch timed on its own (zkp_profile_pairing_dev: a single pipeline, no overlap) against
+        # the multiply-adds that class executes - the table a reader would otherwise rebuild from rocprofv3's kernel stats
+        per_kernel = None
+        if not args.bare and args.kernel in ("auto", "coop") and executed and executed.get("total"):
+            cls_macs = {"k_prep_lines": "k_prep_lines<true>", "k_coop<30,4> miller": "k_coop miller1", "k_coop<24,34> fexp_a": "k_coop fexp_a",
+                        "k_batch_inv": "k_batch_inv (estimate from the source)", "k_ksq": "k_ksq", "k_kdec_a": "k_kdec_a (estimate from the source)",
+                        "k_kdec_b": "k_kdec_b (estimate from the source)", "k_coop<36,24> hard-part step programs": "k_coop<36,24> hard-part step programs",
+                        "k_coop<24,34> phase-C step programs": "k_coop<24,34> phase-C step programs"}
+            try:
+                prof = eng.profile_pairing(g1, g2, out_gt)
+                per_kernel = {"pairs": n, "classes": {}, "sum_ms": sum(v[0] for v in prof.values()),
+                              "what": "one pass with every launch bracketed by HIP events on ONE pipeline (the timed pass overlaps two; its wall time is "
+                                      "kernel_ms): ms and launches per kernel class, executed multiply-adds per pairing of that class "
+                                      "(tools/executed_macs.py) and the share of the peak multiply-add issue (256 CU x 4 SIMD x 16 lanes x 2.4 GHz) it reaches"}
+                for name, (ms_c, cnt) in prof.items():
+                    mc = executed["per_kernel"].get(cls_macs[name])
+                    per_kernel["classes"][name] = {"ms": ms_c, "launches": cnt, "executed_macs_per_pairing": mc,
+                                                   "executed_frac_of_peak": (n * mc / (ms_c * 1e-3) / PEAK_MACS) if (mc and ms_c > 0) else None}
+            except z.ZkpError as ex:
+                per_kernel = {"error": repr(ex)}
         value = global_pairs * args.steps / dt
         achieved = (n * MACS_PER_PAIRING) / (kern_ms * 1e-3)
         phase = lambda fpm, ms: ((n * fpm * MACS_PER_FPMUL) / (ms * 1e-3) / PEAK_MACS) if ms else None
         traffic = traffic_src = None
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             tpath = os.path.join(ROOT, "profiles", rnd, "pmc", "traffic.json")
             if os.path.exists(tpath) and args.kernel in ("auto", "coop"):
                 with open(tpath) as tf:   # rocprofv3 PMC passes over one 2^20-pair pass, gfx950-corrected (tools/pmc_traffic.py); linear in n
@@ -539,7 +559,11 @@ def main():
                          "executed intensity ~30 MAC/B with the line stream and the per-check state that pass through HBM - still 6x above the "
                          "4.9 MAC/B ridge of 39.3 T MAC/s over 8 TB/s)",
                 "achieved": achieved / 1e12, "peak": PEAK_MACS / 1e12, "unit": "T u32-MAC/s",
-                "frac": achieved / PEAK_MACS, "traffic": traffic, "traffic_source": traffic_src,
+                "frac": achieved / PEAK_MACS,
+                "frac_basis": "ALGORITHMIC-equivalent: SURVEY.md 8(d)'s reference-shaped schoolbook count (6.56 M MAC per pairing) over time - it credits "
+                              "work the kernels avoid (lazy reduction, Karatsuba, compressed squarings); executed_frac_of_peak beside it is what the "
+                              "multiply-add pipe actually issues",
+                "traffic": traffic, "traffic_source": traffic_src,
                 "peak_clock_ghz": NOMINAL_GHZ, "sustained_clock_ghz": sustained_ghz,
                 "frac_at_sustained_clock": (achieved / (LANES_PER_CLK * sustained_ghz * 1e9)) if sustained_ghz else None,
                 "kernel_ms": kern_ms, "algorithmic_macs_per_pairing": MACS_PER_PAIRING,
@@ -551,6 +575,7 @@ def main():
                                     "kernels": "k_prep_lines<false> (upstream-shaped lines) + k_coop<30,4> (miller1), Gt-less: Miller value to wire"},
                     "final_exponentiation": {"ms": fe_ms, "frac": phase(FPMUL_FEXP, fe_ms), "fp_mul_equivalents": FPMUL_FEXP,
                                              "kernels": "k_coop<24,34> (fexp_a, fexp_c0..5), k_batch_inv, k_ksq, k_kdec_a, k_kdec_b"}},
+                "kernels_executed": per_kernel,
                 "kernels": {
                     "k_prep_lines": {"ms": prep_ms, "frac": phase(FPMUL_LINES, prep_ms), "fp_mul_equivalents": FPMUL_LINES,
                                      "what": "G2 doubling / addition steps + line coefficients as the fused path runs them (k_prep_lines<true>: homogeneous projective, "

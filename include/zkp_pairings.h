@@ -329,6 +329,15 @@ int zkp_time_pairing_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, size_
  * Queued on a second stream beside a running pass it reports the clock the chip sustains under that load. */
 int zkp_clock_probe_dev(zkp_ctx* ctx, void* stream, unsigned spin_us, void* d_out, int* wall_khz);
 
+/* measurement: ONE pass of the fused pairing over n resident pairs with every kernel launch bracketed by HIP events on its stream
+ * (a single pipeline, so that no two kernels overlap): ms[c] = summed duration and launches[c] = number of the launches of class c.
+ * Cooperative family only.  bench.py prints each class against the multiply-adds it executes (roofline.kernels). */
+#define ZKP_PROFILE_CLASSES 9
+/* 0 k_prep_lines, 1 k_coop<30,4> (Miller program), 2 k_coop<24,34> fexp_a, 3 k_batch_inv, 4 k_ksq, 5 k_kdec_a, 6 k_kdec_b,
+ * 7 k_coop<36,24> (hard-part step programs), 8 k_coop<24,34> (the other step programs of phase C) */
+int zkp_profile_pairing_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out_gt,
+                            float* ms /* ZKP_PROFILE_CLASSES */, int* launches /* ZKP_PROFILE_CLASSES */);
+
 /* diagnostic: time one synthetic step program of the cooperative interpreter (which: 0 T=1, 1 T=3,
  * 2 T=3+epilogue, 3 T=6, 4 T=12, 5 LIN, 6 / 7 cyclotomic squaring without / with companion slots, 8 spill + fill;
  * 9: 400 compressed squarings of k_ksq; 10: the line precomputation k_prep_lines of n pairs; 11: the one-pair Miller

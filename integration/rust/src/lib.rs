@@ -148,6 +148,8 @@ extern "C" {
                                                n: usize, out_gt: *mut u64, is_one: *mut c_int) -> c_int;
     pub fn zkp_take_validation_status_dev(ctx: *mut ZkpCtx, stream: *mut c_void, bad: *mut c_int) -> c_int;
     pub fn zkp_clock_probe_dev(ctx: *mut ZkpCtx, stream: *mut c_void, spin_us: c_uint, d_out: *mut c_void, wall_khz: *mut c_int) -> c_int;
+    pub fn zkp_profile_pairing_dev(ctx: *mut ZkpCtx, d_g1: *const c_void, d_g2: *const c_void, n: usize, d_out_gt: *mut c_void,
+                                   ms: *mut f32, launches: *mut c_int) -> c_int;
     pub fn zkp_time_pairing_dev(ctx: *mut ZkpCtx, d_g1: *const c_void, d_g2: *const c_void, n: usize, d_out_gt: *mut c_void,
                                 reps: c_int, avg_ms: *mut f32) -> c_int;
     pub fn zkp_time_coop_step(ctx: *mut ZkpCtx, which: c_int, n: usize, ms: *mut f32) -> c_int;

@@ -48,24 +48,30 @@ def per_pairing():
     out["k_coop miller1"] = program_macs_per_lane(cg.prog_miller(1, False).steps) * 64 / 5
     out["k_coop fexp_a"] = program_macs_per_lane(cg.prog_fexp_a(False).steps) * 64 / 5
     ksq_body = macs(coopasm.generate_ksq().lines)
-    prog_c = ksq = kdec = inv = 0
+    prog_c = prog_c_deep = ksq = kdec_a = kdec_b = inv = 0
     for st in cg.fexp_c_plan():
         if st[0] == "prog":
-            prog_c += program_macs_per_lane(st[1].steps) * 64 / 5
+            m = program_macs_per_lane(st[1].steps) * 64 / 5
+            if st[1].peak > cg.LDS_SLOTS:                                 # the 36-slot ("deep") LDS configuration: k_coop<36,24>
+                prog_c_deep += m
+            else:
+                prog_c += m
         elif st[0] == cg.PLAN_KSQ:
             ksq += st[3] * ksq_body * 4                                   # four lanes per check
         elif st[0] == cg.PLAN_KDEC_A:
             # per snapshot, two lanes: two Fp2 squarings (2 x (196 + 196)), the zero test's reduction (196), |D|^2 (2 x 196 + 196)
-            kdec += st[2] * 2 * (2 * 392 + 196 + 588)
+            kdec_a += st[2] * 2 * (2 * 392 + 196 + 588)
         elif st[0] == cg.PLAN_KDEC_B:
             # conj(D) / |D|^2 (392), N / D (2 x 196 + 196), t under one reduction (5 x 196 + 196)
-            kdec += st[2] * 2 * (392 + 588 + 1176)
+            kdec_b += st[2] * 2 * (392 + 588 + 1176)
         elif st[0] == cg.PLAN_INV:
             inv += st[3] * 3 * 392                                        # Montgomery's trick: three products per value (+ one shared inversion per 32)
     inv += 3 * 392                                                        # the single inversion of Fp12::invert
-    out["k_coop fexp_c step programs"] = prog_c
+    out["k_coop<36,24> hard-part step programs"] = prog_c_deep
+    out["k_coop<24,34> phase-C step programs"] = prog_c
     out["k_ksq"] = ksq
-    out["k_kdec_a / k_kdec_b (estimate from the source)"] = kdec
+    out["k_kdec_a (estimate from the source)"] = kdec_a
+    out["k_kdec_b (estimate from the source)"] = kdec_b
     out["k_batch_inv (estimate from the source)"] = inv
     out["total"] = sum(out.values())
     return out

@@ -5,8 +5,8 @@
               --output-format csv -d gpurun_out/pmc_sq -- python3 bench.py --steps 1 --warmup 0 --bare
     python3 tools/pmc_summary.py gpurun_out/pmc_sq [more dirs: further counter sets of the same command] > profiles/r02/pmc/pmc_summary.json
 
-k_coop is split by what it runs: the wide (30-slot) instantiation is the Miller program; the 24-slot one runs fexp_a per
-2^16-check chunk (small grids) and the six phase C step programs over the whole batch (large grids).  Derived per group:
+k_coop is split by its template arguments: <30,4> is the Miller program, <36,24> the hard part's step programs behind the compressed
+squaring runs, <24,34> runs fexp_a per 2^16-check chunk (small grids) and the remaining phase C step programs (large grids).  Derived per group:
 VALU instructions per wave, SIMD-cycles per VALU instruction (SQ_WAVE_CYCLES / waves-per-SIMD is not available per
 dispatch, so the figure is SQ_BUSY_CYCLES-free: wave-cycles / VALU instructions of the same waves)."""
 import collections
@@ -14,14 +14,21 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 
 def group(name, grid, big):
-    if "k_coop" in name:
-        if "30" in name.split("k_coop", 1)[1][:12]:
+    m = re.search(r"k_coop<\s*(\d+)\s*,\s*(\d+)\s*>", name)
+    if m:
+        cfg = (int(m.group(1)), int(m.group(2)))         # the instantiation's template arguments (slots, constants), not a substring
+        if cfg == (30, 4):
             return "k_coop<30,4> miller"
-        return "k_coop<24,34> fexp_c step programs" if grid >= big else "k_coop<24,34> fexp_a"
+        if cfg == (36, 24):
+            return "k_coop<36,24> hard-part step programs"
+        if cfg == (24, 34):
+            return "k_coop<24,34> phase-C step programs" if grid >= big else "k_coop<24,34> fexp_a"
+        return "k_coop<%d,%d>" % cfg
     for k in ("k_prep_lines", "k_batch_inv", "k_ksq", "k_kdec_a", "k_kdec_b", "k_g1_mul28", "k_g2_mul28", "k_set_int"):
         if k in name:
             return k

@@ -81,6 +81,7 @@ SIGNATURES = {
     "zkp_host_unregister": (c_int, [c_vp]),
     "zkp_clock_probe_dev": (c_int, [c_vp, c_vp, ctypes.c_uint, c_vp, ctypes.POINTER(c_int)]),
     "zkp_time_coop_step": (c_int, [c_vp, c_int, c_sz, ctypes.POINTER(ctypes.c_float)]),
+    "zkp_profile_pairing_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(c_int)]),
     "zkp_time_pairing_dev": (c_int, [c_vp, c_vp, c_vp, c_sz, c_vp, c_int, ctypes.POINTER(ctypes.c_float)]),
 }
 

@@ -2165,11 +2165,13 @@ namespace zkp {
 
 struct CoopProgDev { uint32_t* hdr; uint32_t* tbl; uint4* rtbl; uint32_t nslot; uint32_t nconst; uint32_t wide; };
 constexpr int MAX_PIPES = 4;
+struct CoopDev;
 struct CoopPipe {            // one in-flight chunk: its own workspace and (for pipes > 0) its own stream
     int4* lines;  size_t lines_bytes;
     int4* state;  size_t state_bytes;
     hipStream_t stream;
     hipEvent_t done;
+    CoopDev* owner;
 };
 struct CoopDev {
     CoopProgDev progs[ZKP_PROG_COUNT];
@@ -2188,6 +2190,24 @@ struct CoopDev {
     int4* vscratch;          // k_g2_valid_fast3: Montgomery limbs of the affine points (2 values x 4 quads per lane)
     size_t vscratch_bytes;
     hipEvent_t ready;
+    // coop_profile_pairing: every launch of one pass bracketed by events on its stream (ONE pipeline, so that no two kernels overlap)
+    struct ProfEv { int cls; hipEvent_t a, b; };
+    std::vector<ProfEv>* prof;     // null: not profiling
+    bool prof_phase_c;
+};
+
+// kernel classes of coop_profile_pairing (include/zkp_pairings.h ZKP_PROFILE_*)
+enum { PROF_PREP = 0, PROF_MILLER, PROF_FEXP_A, PROF_INV, PROF_KSQ, PROF_KDEC_A, PROF_KDEC_B, PROF_C_DEEP, PROF_C_PLAIN, PROF_CLASSES };
+struct ProfScope {
+    CoopDev* d; hipStream_t s; hipEvent_t b = nullptr;
+    ProfScope(CoopDev* d_, hipStream_t s_, int cls) : d(d_), s(s_) {
+        if (!d->prof) return;
+        hipEvent_t a = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
+        (void)hipEventRecord(a, s);
+        d->prof->push_back({cls, a, b});
+    }
+    ~ProfScope() { if (b) (void)hipEventRecord(b, s); }
 };
 
 // The MULACC table of a program with every LDS address resolved per LANE (the asm block of k_coop reads it: no address
@@ -2286,6 +2306,7 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     if (d->inv_lanes < 1) d->inv_lanes = 1;
     ev = getenv("ZKP_COOP_INV_FERMAT");
     d->inv_fermat = ev && atoi(ev) != 0;
+    for (int i = 0; i < MAX_PIPES; i++) d->pipe[i].owner = d;
     for (int i = 0; i < d->n_pipes; i++) {
         if ((e = hipStreamCreateWithFlags(&d->pipe[i].stream, hipStreamNonBlocking)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&d->pipe[i].done, hipEventDisableTiming)) != hipSuccess) return e;
@@ -2363,6 +2384,7 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     static const long lds_pad = getenv("ZKP_COOP_LDS_PAD") ? atol(getenv("ZKP_COOP_LDS_PAD")) : 0;
     if (lds_pad > 0) lds_bytes += (size_t)lds_pad;
     unsigned blocks = (n_checks + GROUPS - 1) / GROUPS;
+    ProfScope prof(d, s, cfg == 1 ? PROF_MILLER : cfg == 2 ? PROF_C_DEEP : d->prof_phase_c ? PROF_C_PLAIN : PROF_FEXP_A);
     if (cfg == 2)
         hipLaunchKernelGGL((k_coop<ZKP_COOP_DEEP_NSLOT, ZKP_COOP_DEEP_NCONST>), dim3(blocks), dim3(64 * WGW), lds_bytes, s, a);
     else if (cfg == 1)
@@ -2396,6 +2418,7 @@ static hipError_t prep(CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, con
     hipStream_t s = pp->stream;
     size_t p0 = base_check * k_in;
     uint32_t n_pairs = n * g;
+    ProfScope prof(pp->owner, s, PROF_PREP);
     static const bool no_cln = getenv("ZKP_PREP_NO_CLN") && atoi(getenv("ZKP_PREP_NO_CLN"));   // A/B knob (value cached, not the pointer)
     if (fused && !no_cln)
         hipLaunchKernelGGL(k_prep_lines<true>, dim3((2 * n_pairs + 63) / 64), dim3(64), 4 * 4 * 64 * sizeof(int4), s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
@@ -2445,7 +2468,7 @@ static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lin
         if (chunk < 320) chunk = 320;
     }
     int pipes = d->n_pipes;
-    if (n_total <= chunk) pipes = 1;
+    if (n_total <= chunk || d->prof) pipes = 1;
     // workspace first: hipMalloc/hipFree synchronise the device, so never (re)allocate between launches
     size_t cmax = n_total < chunk ? n_total : chunk;
     for (int i = 0; i < pipes; i++) {
@@ -2480,9 +2503,11 @@ hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, co
 // nsq compressed squarings of the Fp12 value in state elements [elem_in, elem_in + 12) of every check, snapshots of
 // (z2..z5) after the squarings whose bit is set in snap_mask into 12-element areas from elem_snap on
 static hipError_t run_ksq(hipStream_t s, int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_in, uint32_t elem_snap, uint32_t nsq,
-                          uint64_t snap_mask) {
+                          uint64_t snap_mask, CoopDev* d = nullptr) {
     if (!n_checks || !nsq) return hipSuccess;
     if (snap_mask && nsq > 64) return hipErrorInvalidValue;   // snapshot bits exist for the first 64 squarings only
+    CoopDev none{};
+    ProfScope prof(d ? d : &none, s, PROF_KSQ);
     hipLaunchKernelGGL(k_ksq, dim3((n_checks + KS_CHECKS - 1) / KS_CHECKS), dim3(64), 7 * 64 * sizeof(int4), s, state, n_checks, nc, elem_in, elem_snap, nsq, snap_mask);
     return hipGetLastError();
 }
@@ -2495,6 +2520,7 @@ static hipError_t run_inv(CoopDev* d, hipStream_t s, int4* state, uint32_t n, ui
     uint32_t B = (uint32_t)(total / d->inv_lanes);
     B = B < 1 ? 1 : (B > d->inv_batch ? d->inv_batch : B);
     const size_t lanes = (total + B - 1) / B;
+    ProfScope prof(d, s, PROF_INV);
     hipLaunchKernelGGL(k_batch_inv, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, state, n, nc, B | (d->inv_fermat ? 0x80000000u : 0u), elem_n,
                        elem_ninv, count);
     return hipGetLastError();
@@ -2505,6 +2531,7 @@ static hipError_t run_inv(CoopDev* d, hipStream_t s, int4* state, uint32_t n, ui
 // Everything runs on pp->stream over the n checks whose state starts at pp->state (record stride nc).
 static hipError_t run_fexp_c(CoopDev* d, CoopPipe* pp, uint32_t n, uint32_t nc, uint64_t* wire_out, uint8_t* ok, int* all_ok) {
     hipError_t e;
+    d->prof_phase_c = true;
     for (int i = 0; i < ZKP_FEXP_C_PLAN_LEN; i++) {
         const ZkpPlanStep& ps = ZKP_FEXP_C_PLAN[i];
         switch (ps.kind) {
@@ -2512,25 +2539,30 @@ static hipError_t run_fexp_c(CoopDev* d, CoopPipe* pp, uint32_t n, uint32_t nc, 
                 e = run_prog(d, pp, (int)ps.a, n, nc, 1, nullptr, wire_out, ok, all_ok);
                 break;
             case ZKP_PLAN_KSQ:
-                e = run_ksq(pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, ps.mask);
+                e = run_ksq(pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, ps.mask, d);
                 break;
-            case ZKP_PLAN_KDEC_A:
+            case ZKP_PLAN_KDEC_A: {
+                ProfScope prof(d, pp->stream, PROF_KDEC_A);
                 hipLaunchKernelGGL(k_kdec_a, dim3((unsigned)((2 * (size_t)n * ps.b + 63) / 64)), dim3(64), 0, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c);
                 e = hipGetLastError();
                 break;
+            }
             case ZKP_PLAN_INV:
                 e = run_inv(d, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c);
                 break;
-            case ZKP_PLAN_KDEC_B:
+            case ZKP_PLAN_KDEC_B: {
+                ProfScope prof(d, pp->stream, PROF_KDEC_B);
                 hipLaunchKernelGGL(k_kdec_b, dim3((unsigned)((2 * (size_t)n * ps.b + 63) / 64)), dim3(64), 0, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c);
                 e = hipGetLastError();
                 break;
+            }
             default:
                 e = hipErrorInvalidValue;
         }
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) break;
     }
-    return hipSuccess;
+    d->prof_phase_c = false;
+    return e;
 }
 
 // Final exponentiation in two phases over a super-chunk of checks that share ONE state buffer: phase A per chunk on
@@ -2605,6 +2637,27 @@ hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, c
         if (e != hipSuccess) return e;
         return run_prog(d, pp, ZKP_PROG_FEXP_A_STATE, n, nc, 1, nullptr, nullptr, nullptr, nullptr);
     });
+}
+
+// one pass of the fused pairing with every launch bracketed by events (one pipeline: no two kernels overlap); ms[c] = the
+// summed duration of the launches of class c, launches[c] their number.  Synchronises `s`.
+hipError_t coop_profile_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, size_t n, uint64_t* out_gt, float* ms, int* launches, hipStream_t s) {
+    CoopDev* d = (CoopDev*)st->d_prog;
+    std::vector<CoopDev::ProfEv> evs;
+    d->prof = &evs;
+    hipError_t e = coop_pairing(st, g1, g2, nullptr, nullptr, n, 1, out_gt, nullptr, nullptr, s);
+    d->prof = nullptr;
+    d->prof_phase_c = false;
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = es;
+    for (int c = 0; c < PROF_CLASSES; c++) { ms[c] = 0.f; launches[c] = 0; }
+    for (auto& ev : evs) {
+        float t = 0.f;
+        if (e == hipSuccess && (e = hipEventElapsedTime(&t, ev.a, ev.b)) == hipSuccess) { ms[ev.cls] += t; launches[ev.cls]++; }
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    return e;
 }
 
 // zkp_tower_op_batch on the cooperative family: `ab` holds the n a-records followed by the n b-records (wire format);

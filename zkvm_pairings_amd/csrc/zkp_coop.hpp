@@ -41,6 +41,9 @@ hipError_t coop_fp12_mul_pairs(CoopState* st, uint64_t* buf, size_t m, size_t h,
 hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks,
                         size_t k, uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s);
 
+// measurement: one pass of the fused pairing, ms / launches per kernel class (ZKP_PROFILE_CLASSES of them, include/zkp_pairings.h)
+hipError_t coop_profile_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, size_t n, uint64_t* out_gt, float* ms, int* launches, hipStream_t s);
+
 }  // namespace zkp
 
 // debugging aid: ZKP_DEBUG_ALLOC=<file> appends one line per device / pinned allocation and release (address, bytes, what for), so

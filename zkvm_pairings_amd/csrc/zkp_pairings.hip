@@ -1694,4 +1694,14 @@ int zkp_time_pairing_dev(zkp_ctx* c, const void* g1, const void* g2, size_t n, v
     return ZKP_OK;
 }
 
+
+int zkp_profile_pairing_dev(zkp_ctx* c, const void* g1, const void* g2, size_t n, void* out, float* ms, int* launches) {
+    if (!c || !g1 || !g2 || !out || !ms || !launches || !n || too_many(n)) return ZKP_ERR_ARG;
+    if (!zkp::coop_selected(&c->coop, c->kernel)) { c->err = "zkp_profile_pairing_dev: the cooperative kernel family is not selected"; return ZKP_ERR_ARG; }
+    int rc = bind(c);
+    if (rc) return rc;
+    HostCall hc(c);
+    return coop_rc(c, "coop_profile_pairing", zkp::coop_profile_pairing(&c->coop, (const uint64_t*)g1, (const uint64_t*)g2, n, (uint64_t*)out, ms, launches, c->stream));
+}
+
 }  // extern "C"

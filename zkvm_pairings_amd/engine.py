@@ -620,6 +620,18 @@ class PairingEngine:
         self._chk(self._lib.zkp_time_coop_step(self._h, int(which), int(n), ctypes.byref(ms)))
         return ms.value
 
+    PROFILE_CLASSES = ("k_prep_lines", "k_coop<30,4> miller", "k_coop<24,34> fexp_a", "k_batch_inv", "k_ksq", "k_kdec_a", "k_kdec_b",
+                       "k_coop<36,24> hard-part step programs", "k_coop<24,34> phase-C step programs")
+
+    def profile_pairing(self, g1, g2, out):
+        """one pass of the fused pairing with every launch timed on its own (zkp_profile_pairing_dev) -> {class: (ms, launches)}"""
+        n = self._t_pairs(g1, g2, None, None)
+        self._t_check(out, 72, "out", rows=n)
+        k = len(self.PROFILE_CLASSES)
+        ms, cnt = (ctypes.c_float * k)(), (ctypes.c_int * k)()
+        self._chk(self._lib.zkp_profile_pairing_dev(self._h, self._tp(g1), self._tp(g2), n, self._tp(out), ms, cnt))
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(self.PROFILE_CLASSES)}
+
     def time_pairing(self, g1, g2, out, reps):
         """avg ms per launch of the fused pairing kernel, HIP events on the engine's own stream."""
         n = self._t_pairs(g1, g2, None, None)
