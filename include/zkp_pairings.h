@@ -220,7 +220,13 @@ int zkp_g2_encode_batch_dev(zkp_ctx* ctx, const void* d_g2, const void* d_inf /*
  * zkp_point_status.  ok[c] = (every point of check c is valid AND prod_j e(P_cj, Q_cj) == Gt::identity()); *all_ok = AND over the
  * checks (each may be NULL).  A point that is not valid takes no part in the Miller loop (no arithmetic on garbage); its check
  * fails.  Decoded points, infinity flags and intermediate status bytes stay in the context's workspace in HBM: the host flavour
- * moves only the byte strings up and the status / ok bytes down. */
+ * moves only the byte strings up and the status / ok bytes down.
+ * Validate first, then use (ABI version 4): only the checks whose 2k points are all valid enter the Miller loop and the final
+ * exponentiation - they are listed and gathered on the device, so a check with an invalid point costs its validity tests and nothing
+ * more.  For that the call reads ONE 32-bit count back from the device between the validity kernels and the pairing phase: the
+ * `_dev` flavour is ordered on `stream` like every other `_dev` call, but it blocks the calling thread until the decode / is_valid
+ * kernels have finished (and is therefore not capturable into a hipGraph).  ZKP_POINTS_NO_COMPACT=1 in the environment restores
+ * the never-blocking flow that runs the pairing on every check. */
 typedef enum {
     ZKP_POINT_OK = 0,               /* a point of the r-torsion subgroup, or a well-formed infinity */
     ZKP_POINT_NONCANONICAL = 1,     /* a coordinate >= p */

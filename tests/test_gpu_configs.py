@@ -434,3 +434,51 @@ dist.barrier(); dist.destroy_process_group(); print("RCCL ONE RANK OK")
 '''
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0 and "RCCL ONE RANK OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_points_check_skips_the_pairing_of_invalid_checks(tmp_path):
+    """round 5: checks with an invalid point never enter the Miller loop (validate first, then use - reference src/g1.rs:49-62).  A 2^18
+    batch in which every second check carries one invalid point gives the same status / ok bytes and flag as the round-4 flow
+    (ZKP_POINTS_NO_COMPACT=1, which runs the fused pairing on every check), and takes at most 60 % of the all-valid batch's time."""
+    code = r'''
+import hashlib, json, os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import zkvm_pairings_amd as z
+from zkvm_pairings_amd import configs, synthetic
+eng = z.PairingEngine(0)
+dev = torch.device("cuda", 0)
+n = 1 << 18
+g1, g2, _, _ = synthetic.random_pairs(eng, n, seed=31, device_tensors=True)
+b1, b2 = eng.encode_points_dev(g1, 1), eng.encode_points_dev(g2, 2)
+bad1 = b1.clone(); bad1[::2, 95] ^= 1            # y of every second G1 point: off the curve
+mixed1 = b1.clone(); mixed1[5::7, 0] |= 0x80     # a malformed flag byte here and there (decode status 2)
+st1 = torch.empty(n, dtype=torch.uint8, device=dev); st2 = torch.empty_like(st1)
+ok = torch.empty(n, dtype=torch.uint8, device=dev); flag = torch.empty(1, dtype=torch.int32, device=dev)
+out = {}
+def run(tag, a, k):
+    ok_k = ok[: n // k]
+    eng.points_check(a, b2, k, st1, st2, ok_k, flag); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        eng.points_check(a, b2, k, st1, st2, ok_k, flag)
+    torch.cuda.synchronize()
+    h = hashlib.sha256(st1.cpu().numpy().tobytes() + st2.cpu().numpy().tobytes() + ok_k.cpu().numpy().tobytes()).hexdigest()
+    out[tag] = {"ms": (time.perf_counter() - t0) * 500, "sha": h, "flag": int(flag.item()), "n_bad": int((st1 != 0).sum().item()),
+                "n_ok": int(ok_k.sum().item())}
+run("valid", b1, 1); run("half", bad1, 1); run("mixed_k2", mixed1, 2)
+print(json.dumps(out))
+'''
+    import json
+
+    def go(env):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    new, old = go(dict(os.environ)), go(dict(os.environ, ZKP_POINTS_NO_COMPACT="1"))
+    for tag in ("valid", "half", "mixed_k2"):
+        assert new[tag]["sha"] == old[tag]["sha"] and new[tag]["flag"] == old[tag]["flag"] == 0, tag
+    assert new["half"]["n_bad"] == 1 << 17 and new["valid"]["n_bad"] == 0 and new["mixed_k2"]["n_bad"] > 30000
+    assert new["half"]["ms"] <= 0.60 * new["valid"]["ms"], new
+    assert old["half"]["ms"] > 0.85 * old["valid"]["ms"], old        # the round-4 flow paid for every check

@@ -2587,7 +2587,10 @@ static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_line
         // checks); small ones do better per chunk on the two pipelines (-1 % at 2^17)
         // experiment knob (round 4): phase C in c_split parts on the pipelines' streams, so that one part's latency-bound
         // islands (k_batch_inv, k_kdec_a / _b) can run beside another part's step programs and squaring runs
-        static const int c_split = getenv("ZKP_COOP_C_SPLIT") ? atoi(getenv("ZKP_COOP_C_SPLIT")) : 0;
+        // Round 5: two parts are the default from 2^19 checks on (same-box A/B at 2^20: 234.1 / 236.0 -> 233.4 / 233.4 ms; at 2^17 one
+        // launch sequence is 0.5 % faster, so a rank's shard of the 8-GPU run keeps it).  ZKP_COOP_C_SPLIT=1 switches the split off.
+        static const int c_split_env = getenv("ZKP_COOP_C_SPLIT") ? atoi(getenv("ZKP_COOP_C_SPLIT")) : 0;
+        const int c_split = c_split_env > 0 ? c_split_env : (ns >= ((size_t)1 << 19) && d->n_pipes >= 2 && !d->prof ? 2 : 0);
         if (c_split > 1 && ns > d->c_single_min) {
             const size_t part = ((ns + c_split - 1) / c_split + 15) / 16 * 16;
             e = for_chunks(d, ns, 1, false, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {

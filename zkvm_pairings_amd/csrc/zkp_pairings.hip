@@ -382,6 +382,39 @@ __global__ void k_checks_merge(const uint8_t* st1, const uint8_t* st2, size_t n_
     }
 }
 
+// ---- round 5: no pairing work on checks already known to fail.  k_checks_compact lists the checks whose 2k points are all valid
+// (idx[0 .. *count), any order) and zeroes the ok byte of the others; k_gather_checks copies the listed checks' points next to each
+// other; k_scatter_ok puts the compact ok bytes back.  (wave-aggregated: one atomicAdd per wavefront)
+__global__ void k_checks_compact(const uint8_t* st1, const uint8_t* st2, size_t n_checks, size_t k, uint32_t* idx, uint32_t* count, uint8_t* ok) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool good = false;
+    if (c < n_checks) {
+        uint8_t bad = 0;
+        for (size_t j = 0; j < k; j++) bad |= st1[c * k + j] | st2[c * k + j];
+        good = !bad;
+        if (bad && ok) ok[c] = 0;
+    }
+    const unsigned long long m = __ballot(good);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (good) idx[base + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)c;
+}
+// out[j * words + w] = in[idx[j] * words + w]: `words` 64-bit words (or bytes: T = uint8_t) per check
+template <class T>
+__global__ void k_gather_checks(const T* in, const uint32_t* idx, size_t m, size_t words, T* out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * words) return;
+    const size_t j = i / words, w = i - j * words;
+    out[i] = in[(size_t)idx[j] * words + w];
+}
+__global__ void k_scatter_ok(const uint8_t* okc, const uint32_t* idx, size_t m, uint8_t* ok) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) ok[idx[j]] = okc[j];
+}
+
 // every 6-limb element of a wire buffer must be < p
 __global__ void k_check_canonical(const uint64_t* a, size_t n_fp, int* bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -418,8 +451,9 @@ struct zkp_ctx {
     hipDeviceProp_t prop;
     zkp::CoopState coop;
     // zkp_points_check_batch: decoded points, infinity flags, decode / is_valid / merged status bytes, ok bytes (grow-only)
-    void* pc[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t pc_cap[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void* pc[18] = {};
+    size_t pc_cap[18] = {};
+    uint32_t* h_count = nullptr;   // page-locked word: the number of valid checks comes back through it
     // one-rank-per-GPU communicator (zkp_comm_init_rank); null until then
     ncclComm_t comm = nullptr;
     int comm_nranks = 0, comm_rank = 0;
@@ -787,8 +821,9 @@ void zkp_free(zkp_ctx* c) {
     zkp::coop_free(&c->coop);
     for (int i = 0; i < 8; i++)
         if (c->buf[i]) (void)hipFree(c->buf[i]);
-    for (int i = 0; i < 10; i++)
+    for (int i = 0; i < 18; i++)
         if (c->pc[i]) (void)hipFree(c->pc[i]);
+    if (c->h_count) (void)hipHostFree(c->h_count);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->prod) (void)hipFree(c->prod);
     for (int i = 0; i < 2; i++) {
@@ -995,7 +1030,13 @@ static int ensure_pc(zkp_ctx* c, int slot, size_t bytes) {
     c->pc_cap[slot] = bytes;
     return ZKP_OK;
 }
-enum { PC_G1 = 0, PC_G2, PC_INF1, PC_INF2, PC_DEC, PC_VAL, PC_ST1, PC_ST2, PC_OK, PC_BYTES };
+enum { PC_G1 = 0, PC_G2, PC_INF1, PC_INF2, PC_DEC, PC_VAL, PC_ST1, PC_ST2, PC_OK, PC_BYTES, PC_IDX, PC_CNT, PC_CG1, PC_CG2, PC_CINF1, PC_CINF2, PC_COK };
+// ZKP_POINTS_NO_COMPACT=1 (environment, read once): the round-4 flow - the fused pairing runs on every check, valid or not, and the call
+// never waits on the host (the A/B baseline and the cross-check of the compacted flow)
+static bool points_no_compact() {
+    static const bool v = getenv("ZKP_POINTS_NO_COMPACT") && atoi(getenv("ZKP_POINTS_NO_COMPACT")) != 0;
+    return v;
+}
 static int points_check_dev(zkp_ctx* c, const void* b1, const void* b2, size_t n_checks, size_t k, void* st1, void* st2, void* ok, int* all_ok,
                             hipStream_t s) {
     const size_t np = n_checks * k;
@@ -1020,11 +1061,53 @@ static int points_check_dev(zkp_ctx* c, const void* b1, const void* b2, size_t n
         hipLaunchKernelGGL(k_points_merge, dim3(grid_for(np, 256)), dim3(256), 0, s, dec2, val2, (uint8_t*)c->pc[PC_INF2], np, s2);
         HIPCHK(c, hipGetLastError());
     }
-    if ((rc = pairing_dev(c, (const uint64_t*)c->pc[PC_G1], (const uint64_t*)c->pc[PC_G2], (const uint8_t*)c->pc[PC_INF1], (const uint8_t*)c->pc[PC_INF2],
-                          n_checks, k, nullptr, okb, all_ok, s)))
-        return rc;
-    if (n_checks && k) {
-        hipLaunchKernelGGL(k_checks_merge, dim3(grid_for(n_checks, 256)), dim3(256), 0, s, s1, s2, n_checks, k, okb, all_ok);
+    // Validate first, then use (reference src/g1.rs:49-62: is_valid before anything is done with a point): the checks whose points are
+    // all valid are listed, their number comes back to the host (one 4-byte read-back: the call waits for the decode / is_valid
+    // kernels here - the grids of the pairing phase depend on it), and only those checks enter the Miller loop and the final
+    // exponentiation.  A check with an invalid point costs its validity tests and nothing else.
+    size_t m = n_checks;
+    const bool compact = n_checks && k && !points_no_compact();
+    if (compact) {
+        if ((rc = ensure_pc(c, PC_IDX, n_checks * 4 + 8)) || (rc = ensure_pc(c, PC_CNT, 8))) return rc;
+        if (!c->h_count) HIPCHK(c, hipHostMalloc((void**)&c->h_count, 8, hipHostMallocDefault));
+        HIPCHK(c, hipMemsetAsync(c->pc[PC_CNT], 0, 4, s));
+        hipLaunchKernelGGL(k_checks_compact, dim3(grid_for(n_checks, 256)), dim3(256), 0, s, s1, s2, n_checks, k, (uint32_t*)c->pc[PC_IDX], (uint32_t*)c->pc[PC_CNT], okb);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_count, c->pc[PC_CNT], 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        m = *c->h_count;
+        if (m > n_checks) { c->err = "zkp_points_check: the count of valid checks is out of range"; return ZKP_ERR_HIP; }
+    }
+    if (m == n_checks) {
+        if ((rc = pairing_dev(c, (const uint64_t*)c->pc[PC_G1], (const uint64_t*)c->pc[PC_G2], (const uint8_t*)c->pc[PC_INF1], (const uint8_t*)c->pc[PC_INF2],
+                              n_checks, k, nullptr, okb, all_ok, s)))
+            return rc;
+        if (n_checks && k && !compact) {
+            hipLaunchKernelGGL(k_checks_merge, dim3(grid_for(n_checks, 256)), dim3(256), 0, s, s1, s2, n_checks, k, okb, all_ok);
+            HIPCHK(c, hipGetLastError());
+        }
+        return ZKP_OK;
+    }
+    // some checks failed their validity tests (their ok bytes are 0 already): gather the others, run them, put their ok bytes back
+    const size_t mp = m * k;
+    if (m) {
+        if ((rc = ensure_pc(c, PC_CG1, mp * 96 + 8)) || (rc = ensure_pc(c, PC_CG2, mp * 192 + 8)) || (rc = ensure_pc(c, PC_CINF1, mp + 8)) ||
+            (rc = ensure_pc(c, PC_CINF2, mp + 8)) || (rc = ensure_pc(c, PC_COK, m + 8)))
+            return rc;
+        const uint32_t* idx = (const uint32_t*)c->pc[PC_IDX];
+        hipLaunchKernelGGL(k_gather_checks<uint64_t>, dim3(grid_for(mp * 12, 256)), dim3(256), 0, s, (const uint64_t*)c->pc[PC_G1], idx, m, k * 12, (uint64_t*)c->pc[PC_CG1]);
+        hipLaunchKernelGGL(k_gather_checks<uint64_t>, dim3(grid_for(mp * 24, 256)), dim3(256), 0, s, (const uint64_t*)c->pc[PC_G2], idx, m, k * 24, (uint64_t*)c->pc[PC_CG2]);
+        hipLaunchKernelGGL(k_gather_checks<uint8_t>, dim3(grid_for(mp, 256)), dim3(256), 0, s, (const uint8_t*)c->pc[PC_INF1], idx, m, k, (uint8_t*)c->pc[PC_CINF1]);
+        hipLaunchKernelGGL(k_gather_checks<uint8_t>, dim3(grid_for(mp, 256)), dim3(256), 0, s, (const uint8_t*)c->pc[PC_INF2], idx, m, k, (uint8_t*)c->pc[PC_CINF2]);
+        HIPCHK(c, hipGetLastError());
+        if ((rc = pairing_dev(c, (const uint64_t*)c->pc[PC_CG1], (const uint64_t*)c->pc[PC_CG2], (const uint8_t*)c->pc[PC_CINF1], (const uint8_t*)c->pc[PC_CINF2],
+                              m, k, nullptr, (uint8_t*)c->pc[PC_COK], nullptr, s)))
+            return rc;
+        hipLaunchKernelGGL(k_scatter_ok, dim3(grid_for(m, 256)), dim3(256), 0, s, (const uint8_t*)c->pc[PC_COK], idx, m, okb);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (all_ok) {      // at least one check failed its validity tests: the AND is 0 whatever the pairings say
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, all_ok, 0);
         HIPCHK(c, hipGetLastError());
     }
     return ZKP_OK;
