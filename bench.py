@@ -268,11 +268,13 @@ def main():
     # what a Rust / C host runs, librccl linked into libzkp_pairings.so), outside the timed region and behind a watchdog: a hang or
     # an error here costs the line one field, never the measurement above
     abi_coll, abi_hung = None, False
-    # (ZKP_BENCH_FORCE_ABI_PROBE=1: run the probe on a single rank too - a one-rank communicator; the GPU suite's rehearsal of this code)
+    # (ZKP_BENCH_FORCE_ABI_PROBE=1 switches the probe on: a one-rank communicator on a single rank - the GPU suite's rehearsal of this code)
     if abi_step:
         abi_coll = {"ok": True, "ranks_ok": ranks, "what": "--collective abi: the TIMED step is zkp_pairing_gt_check_batch_allreduce_dev on the library's "
                                                            "communicator (%d ranks); no separate probe" % ranks}
-    elif (world > 1 and backend == "nccl" and not shared_gpu) or (world == 1 and os.environ.get("ZKP_BENCH_FORCE_ABI_PROBE") == "1"):
+    elif os.environ.get("ZKP_BENCH_FORCE_ABI_PROBE") == "1" and (world == 1 or (backend == "nccl" and not shared_gpu)):
+        # opt-in since round 5: a second RCCL communicator beside torch's live one has never run on more than one rank, and a crash in
+        # it would cost the line that is printed below - the ABI path is timed properly by `--collective abi` instead
         import threading
         uid = [z.PairingEngine.comm_unique_id() if rank == 0 else None]
         if world > 1:
@@ -393,6 +395,11 @@ def main():
         value = global_pairs * args.steps / dt
         achieved = (n * MACS_PER_PAIRING) / (kern_ms * 1e-3)
         phase = lambda fpm, ms: ((n * fpm * MACS_PER_FPMUL) / (ms * 1e-3) / PEAK_MACS) if ms else None
+        try:
+            sec_all = executed_macs.secondary()
+        except Exception:
+            sec_all = {}
+        phase_exec = lambda key, ms: ((n * sec_all[key]) / (ms * 1e-3) / PEAK_MACS) if (ms and sec_all.get(key)) else None
         traffic = traffic_src = None
         for rnd in ("r05", "r04", "r03", "r02", "r01"):
             tpath = os.path.join(ROOT, "profiles", rnd, "pmc", "traffic.json")
@@ -415,11 +422,17 @@ def main():
                 return (time.perf_counter() - tw) * 1e3 / reps
 
             secondary = {}
+            try:
+                sec_macs = executed_macs.secondary()      # executed multiply-adds per unit, counted from what the generators emit
+            except Exception:
+                sec_macs = {}
+            exec_frac = lambda key, units, ms: (units * sec_macs[key] / (ms * 1e-3) / PEAK_MACS) if sec_macs.get(key) else None
             nc4 = min(1 << 18, max(1, n // 3))                 # config 4: 2^18 three-pair checks, one shared final exponentiation each
             c4_ms = wall_ms(lambda: eng.pairing_gt_check(g1[:3 * nc4], g2[:3 * nc4], 3, None, ok[:nc4], flag))
             secondary["config4_three_pair_checks"] = {
                 "checks": nc4, "ms": c4_ms, "checks_per_s": nc4 / c4_ms * 1e3, "fp_mul_equivalents_per_check": FPMUL_CHECK3,
                 "frac": nc4 * FPMUL_CHECK3 * MACS_PER_FPMUL / (c4_ms * 1e-3) / PEAK_MACS,
+                "executed_macs_per_check": sec_macs.get("config4_three_pair_check"), "executed_frac_of_peak": exec_frac("config4_three_pair_check", nc4, c4_ms),
                 "macs_source": "SURVEY.md 8(d): Miller(3 pairs) 21,492 + final exponentiation 11,729 Fp-mul-equivalents x 300; "
                                "recomputable from profiles/r04/workloads_a.json (roofline.config4_three_pair_checks)",
                 "what": "multi-Miller loop over 3 pairs (miller3 program: shared squarings) + ONE final exponentiation + identity flag per check; "
@@ -430,9 +443,11 @@ def main():
                 "points": n,
                 "g1": {"ms": v1_ms, "points_per_s": n / v1_ms * 1e3, "fp_mul_equivalents_per_point": FPMUL_G1_VALID,
                        "frac": n * FPMUL_G1_VALID * MACS_PER_FPMUL / (v1_ms * 1e-3) / PEAK_MACS,
+                       "executed_macs_per_point": sec_macs.get("g1_is_valid_point"), "executed_frac_of_peak": exec_frac("g1_is_valid_point", n, v1_ms),
                        "kernel": "k_g1_valid_fast (asm doubling / addition steps, 3 waves per SIMD) + k_g1_valid28 on the points it marks"},
                 "g2": {"ms": v2_ms, "points_per_s": n / v2_ms * 1e3, "fp_mul_equivalents_per_point": FPMUL_G2_VALID,
                        "frac": n * FPMUL_G2_VALID * MACS_PER_FPMUL / (v2_ms * 1e-3) / PEAK_MACS,
+                       "executed_macs_per_point": sec_macs.get("g2_is_valid_point"), "executed_frac_of_peak": exec_frac("g2_is_valid_point", n, v2_ms),
                        "kernel": "k_g2_valid_fast3 (asm steps, two lanes per point, 3 waves per SIMD: X / Z of the running point in LDS) + k_g2_valid28 on the points it marks"},
                 "macs_source": "bench.py FPMUL_G1_VALID / FPMUL_G2_VALID: doubling 2M + 5S, mixed addition 7M + 4S of the inversion-free Jacobian form "
                                "(Fp2: M = 4, S = 2 Fp mul), G1 two chains of 63 + 5 steps, G2 one, + curve equation / endomorphism / comparison, x 300; "
@@ -572,8 +587,10 @@ def main():
                 "executed_frac_of_peak": ((n * executed["total"]) / (kern_ms * 1e-3) / PEAK_MACS) if executed and executed.get("total") else None,
                 "phases": {
                     "miller_loop": {"ms": ml_ms, "frac": phase(FPMUL_MILLER, ml_ms), "fp_mul_equivalents": FPMUL_MILLER,
+                                    "executed_frac_of_peak": phase_exec("multi_miller_loop_pair", ml_ms),
                                     "kernels": "k_prep_lines<false> (upstream-shaped lines) + k_coop<30,4> (miller1), Gt-less: Miller value to wire"},
                     "final_exponentiation": {"ms": fe_ms, "frac": phase(FPMUL_FEXP, fe_ms), "fp_mul_equivalents": FPMUL_FEXP,
+                                             "executed_frac_of_peak": phase_exec("final_exponentiation", fe_ms),
                                              "kernels": "k_coop<24,34> (fexp_a, fexp_c0..5), k_batch_inv, k_ksq, k_kdec_a, k_kdec_b"}},
                 "kernels_executed": per_kernel,
                 "kernels": {

@@ -5,7 +5,7 @@
 # the bench line).  Raw profiler output goes to gpurun_out/prof_<tag>/ (scratch); the summaries are written to
 # gpurun_out/profiles_<tag>/ and copied to profiles/<round>/ by hand after a look.
 set -e -o pipefail
-round=${1:-r04}; tag=${2:-v40}
+round=${1:-r05}; tag=${2:-v51}
 root=$PWD
 raw=$root/gpurun_out/prof_$tag; out=$root/gpurun_out/profiles_$tag
 rm -rf "$raw" "$out"; mkdir -p "$raw" "$out/pmc"
@@ -26,7 +26,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$raw/pmc_write" -- python3 $B
 echo "traffic passes done"
 cd $root
 python3 tools/pmc_summary.py "$raw/pmc_sq1" "$raw/pmc_sq2" > "$out/pmc/pmc_summary.json"
-python3 tools/pmc_traffic.py "$raw/pmc_fetch" "$raw/pmc_write" --pairs 1048576 > "$out/pmc/traffic.json"
+python3 tools/pmc_traffic.py "$raw/pmc_fetch" "$raw/pmc_write" --pairs 1048576 --passes 1 > "$out/pmc/traffic.json"
 for s in sq1:sq_set1 sq2:sq_set2 fetch:fetch_size write:write_size; do
     f=$(find "$raw/pmc_${s%%:*}" -name "*counter_collection.csv" | head -n 1)
     # the per-dispatch rows of the pass's kernels only (the input generation kernels are left out)

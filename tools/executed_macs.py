@@ -77,8 +77,28 @@ def per_pairing():
     return out
 
 
+def secondary():
+    """executed multiply-adds per unit of the other BASELINE configs: a three-pair check of config 4 (three line streams, the miller3 program,
+    one final exponentiation), one G1 / G2 point of config 5's is_valid (asm steps of tools/validasm.py; G1 one lane per point with
+    127 doublings + 16 additions, G2 two lanes per point with 63 + 5; the curve-equation test, endomorphism and comparison are not
+    counted: < 1 %), and multi_miller_loop() of one pair (the upstream-shaped line steps + miller1)"""
+    import validasm
+    base = per_pairing()
+    fexp = sum(v for k, v in base.items() if k not in ("total", "k_prep_lines<true>", "k_coop miller1"))
+    out = {}
+    out["config4_three_pair_check"] = 3 * base["k_prep_lines<true>"] + program_macs_per_lane(cg.prog_miller(3, False).steps) * 64 / 5 + fexp
+    out["g1_is_valid_point"] = 127 * macs(validasm.g1_dbl().lines) + 16 * macs(validasm.g1_madd().lines)
+    out["g2_is_valid_point"] = 2 * (63 * macs(validasm.g2_dbl3().lines) + 5 * macs(validasm.g2_madd3().lines))
+    jac = 2 * (63 * macs(prepasm.generate_jac().lines) + 5 * macs(prepasm.generate_jac_add().lines))
+    out["multi_miller_loop_pair"] = jac + program_macs_per_lane(cg.prog_miller(1, True).steps) * 64 / 5
+    out["final_exponentiation"] = fexp
+    return out
+
+
 if __name__ == "__main__":
     r = per_pairing()
     for k, v in r.items():
         print("%-52s %12.0f" % (k, v))
     print("algorithmic (SURVEY 8d): 6560700; executed / algorithmic = %.3f" % (r["total"] / 6560700))
+    for k, v in secondary().items():
+        print("%-52s %12.0f" % (k, v))

@@ -55,8 +55,10 @@ def main():
     a = ap.parse_args()
     fetch, dfetch = load(a.fetch_dir, "FETCH_SIZE")
     write, dwrite = load(a.write_dir, "WRITE_SIZE")
-    passes = a.passes or dfetch["k_ksq"] // 5      # five x-power chains per pass
-    assert passes and dfetch["k_ksq"] == dwrite["k_ksq"] == 5 * passes, (dfetch, dwrite)
+    # five x-power chains per pass - per PART of phase C (two parts from 2^19 checks on since round 5: pass --passes explicitly then;
+    # `bench.py --steps 1 --warmup 0 --bare` is exactly one pass)
+    passes = a.passes or dfetch["k_ksq"] // 5
+    assert passes and dfetch["k_ksq"] == dwrite["k_ksq"] and dfetch["k_ksq"] % (5 * passes) == 0, (dfetch, dwrite)
     per = {}
     total = 0.0
     for k in PASS_KERNELS:

@@ -17,6 +17,8 @@ __global__ void __launch_bounds__(1024) k(unsigned long long* out, unsigned seed
     unsigned a[16], b[16];
     unsigned long long c[16];
     double d[16];
+    unsigned long long e[16];
+    for (int i = 0; i < 16; i++) e[i] = threadIdx.x * 77u + i;
     for (int i = 0; i < 16; i++) { a[i] = seed * (i + 3) + threadIdx.x; b[i] = seed * (i + 7) ^ threadIdx.x; c[i] = (unsigned long long)a[i] * b[i]; d[i] = (double)a[i]; }
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < ITER; it++) {
@@ -41,11 +43,17 @@ __global__ void __launch_bounds__(1024) k(unsigned long long* out, unsigned seed
             if (KIND == 16) asm volatile("v_pk_mad_u16 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b[i]));
             if (KIND == 17) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b[i]));
             if (KIND == 18) asm volatile("v_mad_u32_u16 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b[i]));
+            // round 5: does an INDEPENDENT cheap instruction hide in the shadow of a multiply-add of the same wavefront?
+            if (KIND == 19) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_add_u32 %1, %1, %3" : "+v"(c[i]), "+v"(a[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]) : "s10", "s11");
+            if (KIND == 20) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_add_u32 %1, %1, %3\n\tv_xor_b32 %1, %1, %2" : "+v"(c[i]), "+v"(a[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]) : "s10", "s11");
+            if (KIND == 21) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_lshl_add_u64 %1, %1, 0, %4" : "+v"(c[i]), "+v"(e[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]), "v"(e[(i + 1) & 15]) : "s10", "s11");
+            if (KIND == 22) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_mul_lo_u32 %1, %1, %3" : "+v"(c[i]), "+v"(a[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]) : "s10", "s11");
+            if (KIND == 23) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_add_u32 %1, %1, %3\n\tv_xor_b32 %1, %1, %2\n\tv_add_u32 %1, %1, %3\n\tv_xor_b32 %1, %1, %2" : "+v"(c[i]), "+v"(a[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]) : "s10", "s11");
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     unsigned long long acc = 0;
-    for (int i = 0; i < 16; i++) acc += a[i] + b[i] + c[i] + (unsigned long long)d[i];
+    for (int i = 0; i < 16; i++) acc += a[i] + b[i] + c[i] + e[i] + (unsigned long long)d[i];
     if ((threadIdx.x & 63) == 0) {
         int w = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
         out[2 * w] = t1 - t0;
@@ -63,13 +71,14 @@ int main() {
         {"v_lshl_add_u64", k<8>}, {"v_add_u32", k<9>}, {"mad_u64_u32+addc pair", k<10>}, {"v_mul_u32_u24", k<11>},
         {"v_mad_i32_i24", k<12>}, {"v_mad_u64_u32 (sgpr carry)", k<13>}, {"v_dot4_u32_u8", k<14>},
         {"v_pk_mul_lo_u16", k<15>}, {"v_pk_mad_u16", k<16>}, {"v_fma_f32", k<17>}, {"v_mad_u32_u16", k<18>},
+        {"mad + 1 indep add_u32", k<19>}, {"mad + add_u32 + xor", k<20>}, {"mad + lshl_add_u64", k<21>}, {"mad + mul_lo_u32", k<22>}, {"mad + 4 simple", k<23>},
     };
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     int cus = prop.multiProcessorCount;
     printf("device %s CUs %d clock %d kHz\n", prop.name, cus, prop.clockRate);
     unsigned long long* dout; CHECK(hipMalloc(&dout, sizeof(unsigned long long) * 2 * 16 * 2 * cus * 4));
     for (auto& e : es) {
-        for (int wps : {1, 2, 4}) {           // waves per SIMD
+        for (int wps : {1, 2, 3, 4}) {           // waves per SIMD
             int threads = 64 * 4 * wps;         // one block per CU fills all 4 SIMDs
             int blocks = cus;
             hipEvent_t ev0, ev1; CHECK(hipEventCreate(&ev0)); CHECK(hipEventCreate(&ev1));
