@@ -285,3 +285,28 @@ def test_division_step_inversion_model():
     hdr = open(os.path.join(ROOT, "zkvm_pairings_amd", "csrc", "zkp_constants28.h")).read()
     assert "#define ZKP30_PINV %du" % sgm.PINV30 in hdr
     assert "#define ZKP30_P_LIMBS %s" % ", ".join(str(x) for x in sgm.PL) in hdr
+
+
+def test_run_time_k_miller_program_matches_the_model():
+    """round 5: the Miller program whose pair count is a LAUNCH argument (a pair loop inside every iteration: one accumulator, the 63
+    squarings shared by all pairs - what checks with more than eight pairs run through) equals the model's multi_miller_loop for
+    k = 1, 3, 9 and 11 pairs (an infinity among them), and the unrolled program where both exist"""
+    g = m.SplitMix64(2026)
+    pts = []
+    for _ in range(11):
+        a, bq = g.below(1 << 200) + 1, g.below(1 << 200) + 1
+        pts.append((m.g1_mul(m.G1_GEN, a), m.g2_mul(m.G2_GEN, bq)))
+    pts[4] = (None, pts[4][1])                         # an infinity: the neutral line
+    prog = cg.prog_miller_n(True)
+    assert sum(1 for st in prog.steps if st["op"] == cg.OP_PLOOP) == sum(1 for st in prog.steps if st["op"] == cg.OP_PENDLOOP) > 5
+    for k in (1, 3, 9, 11):
+        pairs = pts[:k]
+        em = cg.Emu(lines=cg.model_lines(pairs)).run(prog.steps)
+        assert em.cursor == cg.n_line_steps()
+        assert em.wire_out == m.f12_flat_ints(m.multi_miller_loop([p for p in pairs if p[0] is not None])), k
+        if k <= 3:
+            assert em.wire_out == cg.Emu(lines=cg.model_lines(pairs)).run(cg.prog_miller(k, True).steps).wire_out
+    # the encoded program: the pair loop's line loads carry pair 0 (the kernel adds 6 x the loop counter), the loop end moves the cursor
+    hdr, tbl = cg.encode(prog)
+    ops = [hdr[i] & 0xff for i in range(0, len(hdr), 4)]
+    assert ops.count(cg.OP_PLOOP) == ops.count(cg.OP_PENDLOOP) and all(hdr[i + 1] == 1 for i in range(0, len(hdr), 4) if (hdr[i] & 0xff) == cg.OP_PENDLOOP)

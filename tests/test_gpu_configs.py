@@ -482,3 +482,22 @@ print(json.dumps(out))
     assert new["half"]["n_bad"] == 1 << 17 and new["valid"]["n_bad"] == 0 and new["mixed_k2"]["n_bad"] > 30000
     assert new["half"]["ms"] <= 0.60 * new["valid"]["ms"], new
     assert old["half"]["ms"] > 0.85 * old["valid"]["ms"], old        # the round-4 flow paid for every check
+
+
+def test_checks_with_more_than_eight_pairs_share_their_squarings():
+    """round 5: a check of 9..16 pairs runs through ONE accumulator (the run-time-k Miller program), more pairs in groups of 16.  The Miller
+    values equal those of the rounds-1-4 flow (groups of eight joined by f12mul: ZKP_COOP_NO_STREAM=1) for k = 8 .. 96 - and for groups of
+    64 (ZKP_COOP_MAX_STREAM) - and nine-pair checks are faster than that flow (the second group's 63 squarings and the joining product are gone)."""
+    import json
+
+    def go(env):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_kpairs.py"), str(1 << 18)], capture_output=True, text=True, timeout=900,
+                           cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    new, old, wide = go(dict(os.environ)), go(dict(os.environ, ZKP_COOP_NO_STREAM="1")), go(dict(os.environ, ZKP_COOP_MAX_STREAM="64"))
+    assert new["streaming"] and not old["streaming"]
+    for k in (8, 9, 12, 16, 24, 32, 48, 64, 96):
+        assert new["k%d" % k]["sha256"] == old["k%d" % k]["sha256"] == wide["k%d" % k]["sha256"], k
+    assert new["k9"]["ms"] < 0.99 * old["k9"]["ms"], (new["k9"], old["k9"])

@@ -62,6 +62,9 @@ NSLOT = 64             # group-local slots are 0..NSLOT-1; constants are NSLOT..
 CONST_BASE = 64
 
 OP_END, OP_MULACC, OP_LIN, OP_GLOAD, OP_GSTORE, OP_LOOP, OP_ENDLOOP = 0, 1, 2, 3, 4, 5, 6
+# round 5: a loop over the PAIRS of a check (count = the launch's k, a run-time value): the body sees the pair number in its line loads
+OP_PLOOP, OP_PENDLOOP = 7, 8
+PAIR_VAR = -1          # pair index of a K_LINE load inside a pair loop: the loop's counter
 # GLOAD / GSTORE address kinds
 K_LINE, K_STATE, K_WIRE, K_WIRE2 = 0, 1, 2, 3   # K_WIRE2: wire record of check + chk_off (tree reductions)
 
@@ -505,6 +508,13 @@ class Builder:
     def endloop(self):
         self.steps.append({"op": OP_ENDLOOP})
 
+    def ploop(self):
+        self.steps.append({"op": OP_PLOOP})
+
+    def pendloop(self, advance=0):
+        """end of a pair loop; advance: how far the line-stream cursor moves when the loop has run out"""
+        self.steps.append({"op": OP_PENDLOOP, "advance": advance})
+
     # ---- tower macro-ops (lane j produces coefficient j).  dst is a V12 or a slot list; the result
     # is returned as a fresh V12 over those slots (all signs +).
     @staticmethod
@@ -670,6 +680,49 @@ def emit_line_mul(b, f, k):
         f = b.fp12_mul_by_014(f, f, l0, l1, l4, sd_out=f.sd)
     b.release(tmp6)
     return f
+
+
+def emit_line_mul_n(b, f):
+    """the same for a check of ANY number of pairs: a pair loop (count = the launch's k) around ONE load + product; the
+    accumulator and its companions are rewritten in place, so the body is the same for every pair"""
+    tmp6 = b.alloc(6)
+    b.ploop()
+    b.gload(K_LINE, [(tmp6[c], (PAIR_VAR, c)) for c in range(6)])
+    g = b.fp12_mul_by_014(f, f, lin2(tmp6[0], tmp6[1]), lin2(tmp6[2], tmp6[3]), lin2(tmp6[4], tmp6[5]), sd_out=f.sd)
+    assert g.slots == f.slots and all(sg == 1 for sg in getattr(g, "signs", [1] * 12)), "the pair loop's body must map the accumulator to itself"
+    g.sd = f.sd
+    b.pendloop(advance=1)
+    b.release(tmp6)
+    return g
+
+
+def prog_miller_n(to_wire):
+    """multi_miller_loop of one check of k pairs, k a RUN-TIME value (round 5; the launch's k, 9..64 in practice): ONE accumulator,
+    every iteration squares it once and multiplies the lines of all k pairs in (prog_miller unrolls the pairs and exists for k <= 8;
+    more pairs used to run as groups of eight with their own 63 squarings each, joined by f12mul)"""
+    b = Builder()
+    f = b.alloc12()
+    one = CONST_SLOT["ONE"]
+    b.lin([(f.slots[i], Lin.of(one if i == 0 else ZERO)) for i in range(12)])
+    f.sd = b.alloc(12)
+    b.lin([(f.sd[i], Lin.of(one if i < 2 else ZERO)) for i in range(12)])
+    for n_plain, has_add in runs(miller_bits()):
+        body_plain = n_plain - 1 if has_add else n_plain
+        if body_plain > 0:
+            if body_plain > 1:
+                b.loop(body_plain)
+            f = emit_line_mul_n(b, f)
+            f = b.fp12_sqr(f, f, sd_out=f.sd)
+            if body_plain > 1:
+                b.endloop()
+        if has_add:
+            f = emit_line_mul_n(b, f)
+            f = emit_line_mul_n(b, f)
+            f = b.fp12_sqr(f, f, sd_out=f.sd)
+    f = emit_line_mul_n(b, f)
+    b.release(f.sd)
+    finish_output(b, f.conj(), to_wire, ST_F)
+    return b
 
 
 def prog_miller(k, to_wire):
@@ -1132,6 +1185,7 @@ class Emu:
     def run(self, steps):
         pc = 0
         loop_start, loop_left = None, 0
+        ploop_start, ploop_left, pair_var = None, 0, 0
         while pc < len(steps):
             st = steps[pc]
             op = st["op"]
@@ -1142,6 +1196,16 @@ class Emu:
                 if loop_left > 0:
                     pc = loop_start
                     continue
+            elif op == OP_PLOOP:       # count = the launch's k = the pairs of a line-stream step
+                ploop_start, ploop_left, pair_var = pc + 1, len(self.lines[self.cursor]), 0
+            elif op == OP_PENDLOOP:
+                ploop_left -= 1
+                if ploop_left > 0:
+                    pair_var += 1
+                    pc = ploop_start
+                    continue
+                pair_var = 0
+                self.cursor += st.get("advance", 0)
             elif op == OP_MULACC:
                 self.counts["mulacc_steps"] += 1
                 self.counts["P_blocks"] += st["T"]
@@ -1193,7 +1257,7 @@ class Emu:
                 for dst, idx in st["lanes"]:
                     if st["kind"] == K_LINE:
                         pair, c = idx
-                        self.slot[dst] = mont(self.lines[self.cursor][pair][c])
+                        self.slot[dst] = mont(self.lines[self.cursor][pair_var if pair == PAIR_VAR else pair][c])
                     elif st["kind"] == K_STATE:
                         self.slot[dst] = list(self.state[idx])
                     else:
@@ -1522,8 +1586,8 @@ def encode(builder):
                     tbl.append(0)
                 else:
                     slot, idx = ln
-                    if st["kind"] == K_LINE:
-                        idx = idx[0] * 6 + idx[1]
+                    if st["kind"] == K_LINE:      # inside a pair loop the kernel adds 6 x the loop's counter
+                        idx = (0 if idx[0] == PAIR_VAR else idx[0]) * 6 + idx[1]
                     tbl.append(slot | (1 << 7) | (idx << 8))
             arg = st.get("advance", 0) if op == OP_GLOAD else int(st.get("check", False))
             hdr += [op | (st["kind"] << 8), arg, off, 0]
@@ -1531,6 +1595,10 @@ def encode(builder):
             hdr += [op, st["n"], 0, 0]
         elif op == OP_ENDLOOP:
             hdr += [op, 0, 0, 0]
+        elif op == OP_PLOOP:
+            hdr += [op, 0, 0, 0]
+        elif op == OP_PENDLOOP:
+            hdr += [op, st.get("advance", 0), 0, 0]
     hdr += [OP_END, 0, 0, 0]
     return hdr, tbl
 
@@ -1832,6 +1900,8 @@ for _w in ("fp2", "fp6"):
     PROGRAMS["tw_%s_inv_a" % _w] = (lambda w=_w: prog_tower_inv_a(w))
 for _w in ("fp2", "fp6", "fp12"):
     PROGRAMS["tw_%s_inv_b" % _w] = (lambda w=_w: prog_tower_inv_b(w))
+PROGRAMS["millern_state"] = lambda: prog_miller_n(False)
+PROGRAMS["millern_wire"] = lambda: prog_miller_n(True)
 PROGRAMS["tw_to_state"] = prog_tower_to_state
 PROGRAMS["tw_to_snap"] = lambda: prog_tower_to_state(ST_SNAP)
 PROGRAMS["tw_from_snap"] = prog_tower_from_snap

@@ -77,7 +77,8 @@ constexpr int LIG = ZKP_COOP_G;        // 12 lanes per group
 constexpr int ST_SIZE = ZKP_COOP_ST_SIZE;
 constexpr int NLINES = ZKP_COOP_NLINES;
 
-enum { OP_END = 0, OP_MULACC = 1, OP_LIN = 2, OP_GLOAD = 3, OP_GSTORE = 4, OP_LOOP = 5, OP_ENDLOOP = 6 };
+enum { OP_END = 0, OP_MULACC = 1, OP_LIN = 2, OP_GLOAD = 3, OP_GSTORE = 4, OP_LOOP = 5, OP_ENDLOOP = 6,
+       OP_PLOOP = 7, OP_PENDLOOP = 8 };   // round 5: a loop over the k pairs of the launch (run-time count); its counter offsets the line loads
 enum { K_LINE = 0, K_STATE = 1, K_WIRE = 2, K_WIRE2 = 3 };   // K_WIRE2: wire record of check + chk_off
 
 __device__ __constant__ const int32_t K_PBAL[NL] = {ZKP_COOP_P_BAL};
@@ -236,6 +237,8 @@ __global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     const uint32_t* __restrict__ tbl = A.tbl;
     uint32_t cursor = 0;
     int pc = 0, loop_pc = 0, loop_left = 0;
+    int ploop_pc = 0, ploop_left = 0;
+    uint32_t pair6 = 0;      // 6 x the pair loop's counter (0 outside a pair loop): wave-uniform
     auto slot_off = [&](uint32_t s) -> int { return ((s & 64) ? 0 : gbase) + (int)(s & 63); };
     auto ld = [&](int32_t* x, uint32_t s) { lds_ld(x, lds, slot_off(s), PS); };
 
@@ -415,9 +418,9 @@ __global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 } else {
                     size_t rec;
 #ifdef ZKP_EXP_TRAFFIC4L   // timing-only experiment (wrong results): four checks read one line record
-                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + idx) * A.n_checks + (check & ~3u);
+                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + pair6 + idx) * A.n_checks + (check & ~3u);
 #else
-                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + idx) * A.n_checks + check;   // line buffer: this launch's checks only
+                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + pair6 + idx) * A.n_checks + check;   // line buffer: this launch's checks only
 #endif
                     else rec = (size_t)(idx + A.st_off) * A.nc + check;
                     const int4* src = (arg == K_LINE ? A.lines : (const int4*)A.state) + rec * 4;
@@ -486,6 +489,14 @@ __global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             loop_left = (int)h1;
         } else if (op == OP_ENDLOOP) {
             if (--loop_left > 0) { pc = loop_pc; continue; }
+        } else if (op == OP_PLOOP) {
+            ploop_pc = pc + 1;
+            ploop_left = (int)A.k;
+            pair6 = 0;
+        } else if (op == OP_PENDLOOP) {
+            if (--ploop_left > 0) { pair6 += 6; pc = ploop_pc; continue; }
+            pair6 = 0;
+            cursor += h1;
         }
         pc++;
     }
@@ -2408,7 +2419,27 @@ static int miller_prog(size_t k, bool wire) {
     }
 }
 
-constexpr size_t MAX_GROUP = 8;   // pairs per Miller program (shared squarings); a check with more pairs is processed in groups
+constexpr size_t MAX_GROUP = 8;   // pairs per UNROLLED Miller program (miller1..8)
+// round 5: more pairs run through the run-time-k program (millern: a pair loop inside every iteration, ONE accumulator, the 63 squarings
+// shared by all of them) in groups of at most MAX_STREAM pairs; a check with more pairs is joined from its groups' Miller values by
+// f12mul as before.  16 is the measured optimum (multi_miller_loop() of 2^20 / 2^18 pairs in checks of k, same box, ms; groups of 8 |
+// 16 | 64): k = 9: 89.4 | 85.9 | 84.5, 12: 90.6 | 87.9 | 86.7, 16: 85.6 | 87.8 | 85.9, 32: 93.1 | 86.1 | 93.9, 48: 105.0 | 93.6 | 113.1,
+// 64: 107.6 | 102.7 | 116.3, 96: 114.6 | 110.4 | 141.0 (2^18 pairs: 9: 26.5 | 23.0 | 23.3, 16: 27.0 | 25.8 | 25.8, 64: 36.0 | 33.9 | 41.3) -
+// longer groups shrink the chunks the line buffer allows (26 KB per pair) until a launch no longer fills the GPU
+constexpr size_t MAX_STREAM_LIMIT = 64;
+constexpr size_t MAX_STREAM = 16;
+// ZKP_COOP_NO_STREAM=1 (environment, read once): groups of eight pairs joined by f12mul, the flow of rounds 1-4 (A/B baseline, cross-check)
+static bool no_stream() {
+    static const bool v = getenv("ZKP_COOP_NO_STREAM") && atoi(getenv("ZKP_COOP_NO_STREAM")) != 0;
+    return v;
+}
+static size_t max_stream() {
+    // ZKP_COOP_MAX_STREAM (environment, read once): pairs per streamed group, 9 .. 64 (sweeps)
+    static const long env = getenv("ZKP_COOP_MAX_STREAM") ? atol(getenv("ZKP_COOP_MAX_STREAM")) : 0;
+    if (no_stream()) return MAX_GROUP;
+    return env > (long)MAX_GROUP && env <= (long)MAX_STREAM_LIMIT ? (size_t)env : MAX_STREAM;
+}
+static size_t group_size(size_t k) { return k <= MAX_GROUP ? k : (k < max_stream() ? k : max_stream()); }
 bool coop_supports_k(size_t k) { return k >= 1 && k <= 0xffffu; }
 
 // line stream of pairs j0 .. j0+g-1 of each of the n checks starting at base_check (k_in pairs per check)
@@ -2440,10 +2471,16 @@ static hipError_t miller_on_pipe(CoopDev* d, CoopPipe* pp, const uint64_t* g1, c
         if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, 0, (uint32_t)k, fused)) != hipSuccess) return e;
         return run_prog(d, pp, miller_prog(k, wire_out != nullptr), n, nc, (uint32_t)k, nullptr, wire_out, nullptr, nullptr);
     }
-    for (size_t j0 = 0; j0 < k; j0 += MAX_GROUP) {
-        const size_t g = k - j0 < MAX_GROUP ? k - j0 : MAX_GROUP;
+    const size_t MS = max_stream();
+    if (k <= MS) {               // one accumulator for all k pairs
+        if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, 0, (uint32_t)k, fused)) != hipSuccess) return e;
+        return run_prog(d, pp, wire_out ? ZKP_PROG_MILLERN_WIRE : ZKP_PROG_MILLERN_STATE, n, nc, (uint32_t)k, nullptr, wire_out, nullptr, nullptr);
+    }
+    for (size_t j0 = 0; j0 < k; j0 += MS) {
+        const size_t g = k - j0 < MS ? k - j0 : MS;
         if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, (uint32_t)j0, (uint32_t)g, fused)) != hipSuccess) return e;
-        if ((e = run_prog(d, pp, miller_prog(g, false), n, nc, (uint32_t)g, nullptr, nullptr, nullptr, nullptr, j0 ? ZKP_COOP_ST_G : 0)) != hipSuccess)
+        if ((e = run_prog(d, pp, g <= MAX_GROUP ? miller_prog(g, false) : ZKP_PROG_MILLERN_STATE, n, nc, (uint32_t)g, nullptr, nullptr, nullptr, nullptr,
+                          j0 ? ZKP_COOP_ST_G : 0)) != hipSuccess)
             return e;
         if (j0) {
             const bool last = j0 + g == k;
@@ -2464,7 +2501,7 @@ static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lin
     hipError_t e;
     size_t chunk = chunk_override ? chunk_override : d->chunk;
     if (need_lines && k > 4) {   // keep the line buffer at the size four pairs per check need
-        chunk = chunk * 4 / (k < MAX_GROUP ? k : MAX_GROUP);
+        chunk = chunk * 4 / group_size(k);
         if (chunk < 320) chunk = 320;
     }
     int pipes = d->n_pipes;
@@ -2472,7 +2509,7 @@ static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lin
     // workspace first: hipMalloc/hipFree synchronise the device, so never (re)allocate between launches
     size_t cmax = n_total < chunk ? n_total : chunk;
     for (int i = 0; i < pipes; i++) {
-        const size_t kg = k < MAX_GROUP ? k : MAX_GROUP;
+        const size_t kg = group_size(k);
         if (need_lines && (e = ensure_buf(&d->pipe[i].lines, &d->pipe[i].lines_bytes, (size_t)NLINES * kg * 6 * cmax * 64)) != hipSuccess) return e;
         if (need_state && (e = ensure_buf(&d->pipe[i].state, &d->pipe[i].state_bytes, (size_t)ST_SIZE * cmax * 64)) != hipSuccess) return e;
     }
