@@ -178,6 +178,9 @@ class Emu:
     def op_s_waitcnt(self, a, m):
         pass
 
+    def op_s_setprio(self, a, m):
+        pass
+
     def op_s_mov_b32(self, a, m):
         self.s[int(a[0][1:])] = int(a[1], 0) & M32 if not a[1].startswith("s") else self.s[int(a[1][1:])]
 

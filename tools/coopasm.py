@@ -266,6 +266,9 @@ def tail(g, out, fold=True):
             g.e("v_mov_b32 v%d, v%d" % (out + NL - 1, tmp))    # column 27 is empty: the last carry is the top limb
 
 
+SETPRIO = int(os.environ.get("ZKP_GEN_SETPRIO", "0"))
+
+
 def generate(vb=8):
     g = Asm(vb)
     out = g.A[0]
@@ -297,6 +300,9 @@ def generate(vb=8):
     g.e("s_cmp_lt_u32 s%d, %%[T]" % g.sT)
     g.e("s_cbranch_scc1 .Lmloop_%=")
     g.e(".Lmtail_%=:")
+    if SETPRIO:
+        # experiment (round 5): a wavefront in its reduction tail / store section issues ahead of wavefronts in their term loops
+        g.e("s_setprio %d" % SETPRIO)
     g.e("s_waitcnt vmcnt(0)")
     # the step's store words (z, w of the flag row; the flag words themselves are dead): LDS byte address of the result slot and of
     # its companion slot, -1 where the lane stores nothing - requested here, they arrive behind the reduction
@@ -340,6 +346,8 @@ def generate(vb=8):
     g.e("s_mov_b64 exec, s[%d:%d]" % (g.sEX, g.sEX + 1))
     g.e(".Lmdone_%=:")
     g.e("s_waitcnt lgkmcnt(0)")
+    if SETPRIO:
+        g.e("s_setprio 0")
     return g, out
 
 
