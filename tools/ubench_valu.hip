@@ -48,6 +48,11 @@ __global__ void __launch_bounds__(1024) k(unsigned long long* out, unsigned seed
             if (KIND == 20) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_add_u32 %1, %1, %3\n\tv_xor_b32 %1, %1, %2" : "+v"(c[i]), "+v"(a[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]) : "s10", "s11");
             if (KIND == 21) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_lshl_add_u64 %1, %1, 0, %4" : "+v"(c[i]), "+v"(e[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]), "v"(e[(i + 1) & 15]) : "s10", "s11");
             if (KIND == 22) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_mul_lo_u32 %1, %1, %3" : "+v"(c[i]), "+v"(a[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]) : "s10", "s11");
+            // are the 64-bit integer multiply-add and the FP64 / FP32 FMA separate pipes?  (wall time of the pair against the sum of the two alone)
+            if (KIND == 24) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_fma_f64 %1, %1, %4, %1" : "+v"(c[i]), "+v"(d[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]), "v"(d[(i + 1) & 15]) : "s10", "s11");
+            if (KIND == 25) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_fma_f32 %1, %1, %3, %1" : "+v"(c[i]), "+v"(a[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]) : "s10", "s11");
+            if (KIND == 26) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_pk_fma_f32 %1, %1, %4, %1" : "+v"(c[i]), "+v"(e[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]), "v"(e[(i + 1) & 15]) : "s10", "s11");
+            if (KIND == 27) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(e[i]) : "v"(e[(i + 1) & 15]));
             if (KIND == 23) asm volatile("v_mad_u64_u32 %0, s[10:11], %2, %3, %0\n\tv_add_u32 %1, %1, %3\n\tv_xor_b32 %1, %1, %2\n\tv_add_u32 %1, %1, %3\n\tv_xor_b32 %1, %1, %2" : "+v"(c[i]), "+v"(a[i]) : "v"(b[(i + 1) & 15]), "v"(b[i]) : "s10", "s11");
         }
     }
@@ -72,6 +77,7 @@ int main() {
         {"v_mad_i32_i24", k<12>}, {"v_mad_u64_u32 (sgpr carry)", k<13>}, {"v_dot4_u32_u8", k<14>},
         {"v_pk_mul_lo_u16", k<15>}, {"v_pk_mad_u16", k<16>}, {"v_fma_f32", k<17>}, {"v_mad_u32_u16", k<18>},
         {"mad + 1 indep add_u32", k<19>}, {"mad + add_u32 + xor", k<20>}, {"mad + lshl_add_u64", k<21>}, {"mad + mul_lo_u32", k<22>}, {"mad + 4 simple", k<23>},
+        {"mad + fma_f64", k<24>}, {"mad + fma_f32", k<25>}, {"mad + pk_fma_f32", k<26>}, {"v_pk_fma_f32", k<27>},
     };
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     int cus = prop.multiProcessorCount;
