@@ -177,7 +177,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
-            ctl = dist.new_group(backend="gloo")
+            if os.environ.get("ZKP_BENCH_FORCE_ABI_PROBE") == "1":     # only the opt-in probe needs the second group: the default run
+                ctl = dist.new_group(backend="gloo")                   # depends on nothing but torch's RCCL communicator
         else:
             dist.init_process_group(backend)
 
