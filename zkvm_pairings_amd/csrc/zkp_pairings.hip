@@ -448,7 +448,6 @@ struct zkp_ctx {
     } hs[2];
     hipStream_t s_in = nullptr, s_out = nullptr;
     size_t host_slice = (size_t)1 << 19;
-    bool host_slice_fixed = false;   // ZKP_HOST_SLICE given: the same slice length for page-locked and pageable arrays
     hipDeviceProp_t prop;
     zkp::CoopState coop;
     // zkp_points_check_batch: decoded points, infinity flags, decode / is_valid / merged status bytes, ok bytes (grow-only)
@@ -644,19 +643,7 @@ int ensure_slot(zkp_ctx* c, zkp_ctx::HostSlot* h, int which, size_t bytes) {
 // out_gt / ok / all_ok are host pointers, each optional.
 int host_sliced_impl(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks, size_t k,
                      uint64_t* out_gt, uint8_t* ok, int* all_ok) {
-    // slice length: page-locked arrays (zkp_host_alloc / zkp_host_register) copy by DMA beside the kernels - long slices keep the
-    // kernels efficient; from PAGEABLE memory every copy blocks the calling thread, and what is left exposed at the end of the call is
-    // the last slice's download: half the slice there (round 5, same box, 2^20 pairs with Gt out: 290-311 -> 288 ms pageable;
-    // page-locked 252 ms with the long slices, 255-257 with the short ones).  ZKP_HOST_SLICE fixes the length for both.
-    size_t slice = c->host_slice;
-    if (!c->host_slice_fixed) {
-        hipPointerAttribute_t at;
-        const void* probe = out_gt ? (const void*)out_gt : (const void*)g1;
-        const bool locked = hipPointerGetAttributes(&at, probe) == hipSuccess && at.type != hipMemoryTypeUnregistered;
-        (void)hipGetLastError();                      // an unknown host pointer is not an error of this call
-        if (!locked) slice /= 2;
-    }
-    const size_t sc = slice / k ? slice / k : 1;   // checks per slice
+    const size_t sc = c->host_slice / k ? c->host_slice / k : 1;   // checks per slice
     const size_t nsl = (n_checks + sc - 1) / sc;
     int rc;
     if (!c->s_in) {
@@ -816,7 +803,6 @@ int zkp_init(int device, zkp_ctx** out_ctx) {
     if (const char* hsl = getenv("ZKP_HOST_SLICE")) {
         c->host_slice = (size_t)atol(hsl);
         if (c->host_slice < 64) c->host_slice = 64;
-        c->host_slice_fixed = true;
     }
     const char* env = getenv("ZKP_KERNEL");
     if (env) {
