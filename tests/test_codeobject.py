@@ -41,7 +41,9 @@ def test_hot_kernels_keep_their_registers():
     assert prep["vgpr"] <= 256 and prep["spill"] == 0 and prep["scratch"] == 0, prep
     for name in ("k_kdec_a", "k_kdec_b"):
         (v,) = find(name)
-        assert v["vgpr"] <= 168 and v["spill"] == 0, (name, v)
+        # round 5: k_kdec_b keeps z2 across its two by-value products (the denominator is no longer stored a second time): 170 registers
+        # unbounded, 168 + three spilled under __launch_bounds__(64, 3) - measured faster than two waves (3.40 against 3.50 ms per pass)
+        assert v["vgpr"] <= 168 and v["spill"] <= (3 if name == "k_kdec_b" else 0), (name, v)
     for name in ("k_g1_valid28", "k_g2_valid28"):
         (v,) = find(name)
         assert v["spill"] == 0, (name, v)

@@ -1429,8 +1429,7 @@ def emu_kdec_a(state, elem_snap, count, elem_n):
         if not z2_zero:
             n = _c_lin(n, n, 1)
             n = _c_lin(n, n, 1)
-        state[base + 8], state[base + 9] = N
-        state[base + 0], state[base + 1] = D
+        state[base + 8], state[base + 9] = N            # (the kernel tags the record's padding with z2_zero: D itself is not stored)
         state[elem_n + sn] = n
     return state
 
@@ -1448,7 +1447,8 @@ def emu_kdec_b(state, elem_snap, count, elem_ninv):
     for sn in range(count):
         base = elem_snap + 12 * sn
         N = (state[base + 8], state[base + 9])
-        D = (state[base + 0], state[base + 1])
+        z2, z3 = _snap_fp2(state, base, 3), _snap_fp2(state, base, 2)
+        D = z3 if c2_is_zero(z2) else z2                 # k_kdec_a's tag in N's record: which of the two the denominator is
         ninv = state[elem_ninv + sn]
         dinv = (mont_mul([(D[0], ninv)]), mont_mul([([-x for x in D[1]], ninv)]))
         z1 = c2_mul(N, dinv)

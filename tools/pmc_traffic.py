@@ -77,7 +77,8 @@ def main():
                      if st["op"] in (coopgen.OP_GLOAD, coopgen.OP_GSTORE) and st["kind"] == coopgen.K_STATE)
     n = a.pairs
     lines = 68 * 6 * 64 * 2
-    state = (12 + 12 + 9 + 2 + prog_state + 5 * (8 + 48 + 6 * 13 + 18 + 6 * 17)) * 64
+    # round 4 on: three snapshots per chain; round 5: k_kdec_a 8 loads + 3 stores (N twice, n), k_kdec_b 11 loads + 4 stores
+    state = (12 + 12 + 9 + 2 + prog_state + 5 * (8 + 3 * 8 + 3 * 11 + 9 + 3 * 15)) * 64
     algo = n * (288 + 576 + 1 + lines + state)
     out = {
         "workload": "bench.py pass: %d pairs, cooperative family; passes in the profiled run: %d" % (n, passes),

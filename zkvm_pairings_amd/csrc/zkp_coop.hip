@@ -2012,8 +2012,9 @@ __global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks
 //     z2 != 0:  z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2)          z2 == 0:  z1 = 2 z4 z5 / z3   (0 / 0 := 0: the identity)
 //     z0 = (2 z1^2 + z2 z5 - 3 z3 z4) xi + 1
 // Two lanes per (snapshot, check) - lane parity = Fp2 coefficient, as in k_prep_lines.  k_kdec_a leaves the numerator N in the
-// snapshot's z1 records, the denominator D (z2 or z3) in its z0 records and n = |D|^2 (x 4 where D = z2) in plane
-// elem_n + snapshot; k_batch_inv inverts the planes; k_kdec_b finishes: 1 / D = conj(D) / |D|^2.
+// snapshot's z1 records and n = |D|^2 (x 4 where D = z2) in plane elem_n + snapshot; k_batch_inv inverts the planes; k_kdec_b
+// finishes: 1 / D = conj(D) / |D|^2.  The denominator D is z2 or z3 itself: since round 5 it is not stored a second time - which of
+// the two it is travels in the padding of N's record (third dword of the last quad), and k_kdec_b reads z2 and z3 anyway.
 __global__ void __launch_bounds__(64, 2) k_kdec_a(int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_snap, uint32_t count, uint32_t elem_n) {
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
     const int c = (int)(tid & 1);
@@ -2053,15 +2054,18 @@ __global__ void __launch_bounds__(64, 2) k_kdec_a(int4* state, uint32_t n_checks
     acc_reduce(n.l, acc);
     if (!z2_zero) n = c_dbl(c_dbl(n));
     if (live) {
-        rec_store(rec(base + 8 + c), N);
-        rec_store(rec(base + c), D);
+        int4* dn = rec(base + 8 + c);
+        dn[0] = make_int4(N.l[0], N.l[1], N.l[2], N.l[3]);
+        dn[1] = make_int4(N.l[4], N.l[5], N.l[6], N.l[7]);
+        dn[2] = make_int4(N.l[8], N.l[9], N.l[10], N.l[11]);
+        dn[3] = make_int4(N.l[12], N.l[13], z2_zero ? 1 : 0, 0);       // the tag: D = z3 (1) or z2 (0)
         if (c == 0) rec_store(rec(elem_n + sn), n);
     }
 }
 #ifndef ZKP_KDEC_MERGED
 #define ZKP_KDEC_MERGED 1
 #endif
-__global__ void __launch_bounds__(64, 2) k_kdec_b(int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_snap, uint32_t count, uint32_t elem_ninv) {
+__global__ void __launch_bounds__(64, 3) k_kdec_b(int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_snap, uint32_t count, uint32_t elem_ninv) {
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
     const int c = (int)(tid & 1);
     uint32_t e = tid >> 1;
@@ -2077,10 +2081,24 @@ __global__ void __launch_bounds__(64, 2) k_kdec_b(int4* state, uint32_t n_checks
     const uint32_t base = elem_snap + 12 * sn;
     auto rec = [&](uint32_t el) -> int4* { return st + (size_t)el * nc * 4; };
     F2 f{c};
-    Fp28 N, D, ninv;
-    rec_load(N, rec(base + 8 + c));
-    rec_load(D, rec(base + c));
+    Fp28 N, D, ninv, z2, z3;
+    int d_is_z3;
+    {
+        const int4* sn_ = rec(base + 8 + c);
+        const int4 v0 = sn_[0], v1 = sn_[1], v2 = sn_[2], v3 = sn_[3];
+        N.l[0] = v0.x; N.l[1] = v0.y; N.l[2] = v0.z; N.l[3] = v0.w; N.l[4] = v1.x; N.l[5] = v1.y; N.l[6] = v1.z; N.l[7] = v1.w;
+        N.l[8] = v2.x; N.l[9] = v2.y; N.l[10] = v2.z; N.l[11] = v2.w; N.l[12] = v3.x; N.l[13] = v3.y;
+        d_is_z3 = v3.z;                                                 // k_kdec_a's tag
+    }
+    rec_load(z2, rec(base + 6 + c));
     rec_load(ninv, rec(elem_ninv + sn));
+    D = z2;
+    if (__any(d_is_z3 != 0)) {       // wave-uniform and almost never taken (z2 = 0: the identity, pairs with an infinity): D = z3
+        Fp28 z3e;
+        rec_load(z3e, rec(base + 4 + c));
+#pragma unroll
+        for (int i = 0; i < NL; i++) D.l[i] = d_is_z3 ? z3e.l[i] : z2.l[i];
+    }
     Fp28 dinv = f_mul_v(c ? c_neg(D) : D, ninv);               // conj(D) / |D|^2
     Fp28 z1 = f.mul(N, dinv);
 #if ZKP_KDEC_MERGED
@@ -2115,13 +2133,12 @@ __global__ void __launch_bounds__(64, 2) k_kdec_b(int4* state, uint32_t n_checks
             acc_mul(acc, x, y);
         }
         {
-            Fp28 z2, z5;
-            rec_load(z2, rec(base + 6 + c));
+            Fp28 z5;
             rec_load(z5, rec(base + 10 + c));
             mulacc(z2, z5, 1);
         }
         {
-            Fp28 z3, z4;
+            Fp28 z4;
             rec_load(z3, rec(base + 4 + c));
             rec_load(z4, rec(base + 2 + c));
             mulacc(z3, z4, -3);
@@ -2131,8 +2148,7 @@ __global__ void __launch_bounds__(64, 2) k_kdec_b(int4* state, uint32_t n_checks
     Fp28 o;
     swap_pair(o, t);
 #else
-    Fp28 z2, z3, z4, z5;
-    rec_load(z2, rec(base + 6 + c));
+    Fp28 z4, z5;
     rec_load(z5, rec(base + 10 + c));
     Fp28 t = c_add(c_dbl(f.sqr(z1)), f.mul(z2, z5));
     rec_load(z3, rec(base + 4 + c));
