@@ -369,8 +369,8 @@ def main():
             em = executed_macs.per_pairing()
             executed = {"total": em["total"], "per_kernel": {k: v for k, v in em.items() if k != "total"},
                         "source": "tools/executed_macs.py: v_mad_[iu]64_[iu]32 instructions of the generated asm blocks, T x 147 + 196 per MULACC step of "
-                                  "the step programs, x lanes issued (a wavefront issues for all 64 lanes); the compiled decompression / inversion "
-                                  "kernels are estimates from their source"}
+                                  "the step programs, x lanes that execute (the interpreter's wavefronts: 60 - lanes 60..63 are switched off since round 5; rounds "
+                                  "1-4 counted 64); the compiled decompression / inversion kernels are estimates from their source"}
         except Exception as ex:      # the counter needs tools/ and tests/golden/ of the repository
             executed = {"total": None, "error": repr(ex)}
         # per kernel class: one pass with every launch timed on its own (zkp_profile_pairing_dev: a single pipeline, no overlap) against

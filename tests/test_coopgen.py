@@ -265,13 +265,13 @@ def test_executed_multiply_add_count():
     import executed_macs
     r = executed_macs.per_pairing()
     assert abs(r["total"] - sum(v for k, v in r.items() if k != "total")) < 1
-    assert 4.5e6 < r["total"] < 5.6e6 < 6560700
+    assert 4.4e6 < r["total"] < 5.6e6 < 6560700
     assert r["k_coop miller1"] > r["k_ksq"] > r["k_coop<36,24> hard-part step programs"] > r["k_prep_lines<true>"] > r["k_coop<24,34> phase-C step programs"] > r["k_coop fexp_a"]
     # the other BASELINE configs (bench.py secondary_workloads.*.executed_frac_of_peak): the subgroup checks execute what the algorithmic
     # count prices (bench.py FPMUL_G1_VALID / FPMUL_G2_VALID x 300) to within 6 % - their algorithmic fraction has no Karatsuba / lazy slack
     s2 = executed_macs.secondary()
     assert 0.94 < s2["g1_is_valid_point"] / (1002 * 300) < 1.06 and 0.90 < s2["g2_is_valid_point"] / (1346 * 300) < 1.0
-    assert 0.75 < s2["config4_three_pair_check"] / (33221 * 300) < 0.82 and s2["multi_miller_loop_pair"] > r["k_coop miller1"]
+    assert 0.72 < s2["config4_three_pair_check"] / (33221 * 300) < 0.82 and s2["multi_miller_loop_pair"] > r["k_coop miller1"]
     # a Karatsuba block is 147 multiply-adds, a reduction 196: the Fp12 product step of the interpreter
     prod = [st for st in cg.prog_tower("fp12_mul").steps if st["op"] == cg.OP_MULACC and st["T"] == 12]
     assert prod and executed_macs.program_macs_per_lane(prod) == len(prod) * (12 * 147 + 196)

@@ -5,7 +5,8 @@ SURVEY.md 8(d) asks for beside the algorithmic 6,560,700 (which prices the refer
   * asm blocks (tools/prepasm.py, tools/coopasm.py): the v_mad_i64_i32 / v_mad_u64_u32 instructions of the generated text x the
     lanes that issue them (a wavefront issues for all 64 lanes, idle or not);
   * step programs (tools/coopgen.py): per MULACC step and lane T Karatsuba product blocks (147) + one Montgomery reduction (196),
-    walked with the programs' loop counts; 64 lanes per wavefront of 5 checks (lanes 60..63 and padding lanes issue too);
+    walked with the programs' loop counts; 60 executing lanes per wavefront of 5 checks (padding lanes of a step issue too; lanes 60..63
+    are switched off since round 5);
   * the compiled kernels of the decompression and the batched inversions: products counted from their source (196 per schoolbook
     product block, 196 per reduction), an estimate marked as such.
 
@@ -19,6 +20,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import coopasm  # noqa: E402
 import coopgen as cg  # noqa: E402
 import prepasm  # noqa: E402
+
+# lanes of an interpreter wavefront that execute: 5 checks x 12 lanes.  Lanes 60..63 own nothing; until round 4 they ran every instruction
+# on a neighbour's operands (64 lanes issued), since round 5 they leave the kernel at its start (zkp_coop.hip, ZKP_COOP_IDLE_LANES_OFF)
+COOP_LANES = 60
 
 MAD = re.compile(r"^\s*v_mad_[iu]64_[iu]32\b")
 
@@ -45,13 +50,13 @@ def per_pairing():
     out = {}
     dbl, add = macs(prepasm.generate().lines), macs(prepasm.generate_add().lines)
     out["k_prep_lines<true>"] = 2 * (63 * dbl + 5 * add)                 # two lanes per pair
-    out["k_coop miller1"] = program_macs_per_lane(cg.prog_miller(1, False).steps) * 64 / 5
-    out["k_coop fexp_a"] = program_macs_per_lane(cg.prog_fexp_a(False).steps) * 64 / 5
+    out["k_coop miller1"] = program_macs_per_lane(cg.prog_miller(1, False).steps) * COOP_LANES / 5
+    out["k_coop fexp_a"] = program_macs_per_lane(cg.prog_fexp_a(False).steps) * COOP_LANES / 5
     ksq_body = macs(coopasm.generate_ksq().lines)
     prog_c = prog_c_deep = ksq = kdec_a = kdec_b = inv = 0
     for st in cg.fexp_c_plan():
         if st[0] == "prog":
-            m = program_macs_per_lane(st[1].steps) * 64 / 5
+            m = program_macs_per_lane(st[1].steps) * COOP_LANES / 5
             if st[1].peak > cg.LDS_SLOTS:                                 # the 36-slot ("deep") LDS configuration: k_coop<36,24>
                 prog_c_deep += m
             else:
@@ -86,11 +91,11 @@ def secondary():
     base = per_pairing()
     fexp = sum(v for k, v in base.items() if k not in ("total", "k_prep_lines<true>", "k_coop miller1"))
     out = {}
-    out["config4_three_pair_check"] = 3 * base["k_prep_lines<true>"] + program_macs_per_lane(cg.prog_miller(3, False).steps) * 64 / 5 + fexp
+    out["config4_three_pair_check"] = 3 * base["k_prep_lines<true>"] + program_macs_per_lane(cg.prog_miller(3, False).steps) * COOP_LANES / 5 + fexp
     out["g1_is_valid_point"] = 127 * macs(validasm.g1_dbl().lines) + 16 * macs(validasm.g1_madd().lines)
     out["g2_is_valid_point"] = 2 * (63 * macs(validasm.g2_dbl3().lines) + 5 * macs(validasm.g2_madd3().lines))
     jac = 2 * (63 * macs(prepasm.generate_jac().lines) + 5 * macs(prepasm.generate_jac_add().lines))
-    out["multi_miller_loop_pair"] = jac + program_macs_per_lane(cg.prog_miller(1, True).steps) * 64 / 5
+    out["multi_miller_loop_pair"] = jac + program_macs_per_lane(cg.prog_miller(1, True).steps) * COOP_LANES / 5
     out["final_exponentiation"] = fexp
     return out
 

@@ -224,6 +224,15 @@ __global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
 
     for (int i = lane; i < (int)A.nconst * 4; i += 64 * WGW) lds[(i & 3) * PS + (i >> 2)] = A.consts[i];
     __syncthreads();
+#ifndef ZKP_COOP_IDLE_LANES_OFF
+#define ZKP_COOP_IDLE_LANES_OFF 1
+#endif
+#if ZKP_COOP_IDLE_LANES_OFF
+    // round 5: lanes 60..63 of a one-wavefront workgroup own nothing (five checks of twelve lanes) - they used to run every instruction
+    // on group 4's operands and store nothing.  They leave here: EXEC never holds them again (every asm block restores the EXEC it was
+    // entered with; no DPP or ballot of a live lane reads them: they are a quad of their own), and their multiply-adds stop drawing power.
+    if (WGW == 1 && lane >= GROUPS * LIG) return;
+#endif
 #if ZKP_COOP_ASM
     // the lanes that own a coefficient of a live check: wave-uniform (two SGPRs), the store mask of the asm MULACC block
     ZKP_LANE_CTX();
