@@ -2649,10 +2649,11 @@ static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_line
         // checks); small ones do better per chunk on the two pipelines (-1 % at 2^17)
         // experiment knob (round 4): phase C in c_split parts on the pipelines' streams, so that one part's latency-bound
         // islands (k_batch_inv, k_kdec_a / _b) can run beside another part's step programs and squaring runs
-        // Round 5: two parts are the default from 2^19 checks on (same-box A/B at 2^20: 234.1 / 236.0 -> 233.4 / 233.4 ms; at 2^17 one
-        // launch sequence is 0.5 % faster, so a rank's shard of the 8-GPU run keeps it).  ZKP_COOP_C_SPLIT=1 switches the split off.
+        // Round 5: two parts are the default from 2^18 checks on (same-box A/B, one sequence -> two parts: 2^20 234.1 / 236.0 -> 233.4 /
+        // 233.4 ms; 2^19 117.7 / 117.5 -> 115.1 / 114.8; 2^18 60.2 / 60.1 -> 59.1 / 58.6; 2^17 30.9 / 30.5 -> 30.5 / 30.6: a wash, so a
+        // rank's shard of the 8-GPU run keeps the single sequence).  ZKP_COOP_C_SPLIT=1 switches the split off.
         static const int c_split_env = getenv("ZKP_COOP_C_SPLIT") ? atoi(getenv("ZKP_COOP_C_SPLIT")) : 0;
-        const int c_split = c_split_env > 0 ? c_split_env : (ns >= ((size_t)1 << 19) && d->n_pipes >= 2 && !d->prof ? 2 : 0);
+        const int c_split = c_split_env > 0 ? c_split_env : (ns >= ((size_t)1 << 18) && d->n_pipes >= 2 && !d->prof ? 2 : 0);
         if (c_split > 1 && ns > d->c_single_min) {
             const size_t part = ((ns + c_split - 1) / c_split + 15) / 16 * 16;
             e = for_chunks(d, ns, 1, false, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
