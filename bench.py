@@ -352,10 +352,15 @@ def main():
             ml_ms, ml = timed_ms(lambda: eng.multi_miller_loop(g1, g2, 1))
             fe_ms, _ = timed_ms(lambda: eng.final_exponentiation(ml))
             del ml
-            # clock the chip sustains under this load: a one-wavefront probe on a second stream beside a pass
+            # clock the chip sustains under this load: a one-wavefront probe on a second stream beside a pass.  The probe is queued FIRST
+            # (it starts at once and spins for a fixed wall time, half a pass) and two passes behind it: queued behind the pass it could
+            # be held back until the pass's streams had drained - and then read the idle clock (round 5: with phase C on the pipelines'
+            # streams it did, 2.40 GHz on every box)
             side = torch.cuda.Stream(device=dev)
-            eng.pairing_gt_check(g1, g2, 1, out_gt, ok, flag)
+            torch.cuda.synchronize()
             ticks, wall_khz = eng.clock_probe(side, spin_us=max(20000, int(kern_ms * 500)))
+            eng.pairing_gt_check(g1, g2, 1, out_gt, ok, flag)
+            eng.pairing_gt_check(g1, g2, 1, out_gt, ok, flag)
             torch.cuda.synchronize()
             tk = ticks.cpu().numpy()
             sustained_ghz = float(tk[0]) / float(tk[1]) * wall_khz * 1e3 / 1e9 if tk[1] > 0 else None
