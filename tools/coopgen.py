@@ -20,6 +20,7 @@ HIP interpreter performs (14 signed 28-bit limbs, 64-bit columns, R = 2^392), as
 column leaves 63 bits and no limb leaves 31 bits, and (3) writes zkvm_pairings_amd/csrc/zkp_coop_prog.inc.
 The emulator is checked against tests/golden/bls12_381_model.py in tests/test_coopgen.py.
 """
+import collections
 import os
 import sys
 
@@ -288,6 +289,92 @@ def merge_terms(bil):
     return [(a, b) for a, b in by_b.values() if a and b]
 
 
+# round 5: ZKP_GEN_SHARE_FETCHES=1 regenerates the programs with the term order that shares operand fetches (measured: no gain; default off)
+SHARE_FETCHES = int(os.environ.get("ZKP_GEN_SHARE_FETCHES", "0"))
+
+
+def fetch_records(lanes):
+    """LDS records the twelve lanes of a check fetch in one step, a record counted once per term position however many lanes read it
+    (lanes that read one address are served by one bank access): what the operand fetches cost in LDS bank reads"""
+    T = max(len(l["terms"]) for l in lanes)
+    n = 0
+    for t in range(T):
+        recs = set()
+        for l in lanes:
+            if t < len(l["terms"]):
+                a1, a2, _, b1, b2, _, _, _ = l["terms"][t]
+                recs.update((("a", a1), ("b", b1)))
+                if a2 != ZERO:
+                    recs.add(("a", a2))
+                if b2 != ZERO:
+                    recs.add(("b", b2))
+        n += len(recs)
+    return n
+
+
+_SHARE_CACHE = {}
+
+
+def share_operand_fetches(lanes, iters=12000):
+    """Reorder every lane's terms - inside the classes the sort above made (negated / second-operand terms keep their positions'
+    class, so the step's wave-uniform term flags do not change) - so that at each term position the lanes of a check read as FEW
+    distinct LDS records as possible: the sum of a step's products does not depend on their order, but what the operand fetches
+    cost (power: DESIGN section 4, round 5) does - lanes that read one address share one bank access.  The typical gain: the two
+    lanes of an Fp2 coefficient take a b from the SAME record at the same position (a_re b_re beside a_im b_re, then -a_im b_im beside
+    a_re b_im) instead of each its own.  Deterministic hill climbing over swaps of two terms of a lane (seeded by nothing but the
+    step: the same step always gets the same order; identical steps of different programs are solved once)."""
+    import random
+    key = lambda x: (bool(x[6]), x[1] != ZERO, x[4] != ZERO)
+    sig = tuple(tuple(l["terms"]) for l in lanes)
+    if sig in _SHARE_CACHE:
+        for l, terms in zip(lanes, _SHARE_CACHE[sig]):
+            l["terms"] = list(terms)
+        return fetch_records(lanes)
+
+    def recs_of(term):
+        a1, a2, _, b1, b2, _, _, _ = term
+        r = {("a", a1), ("b", b1)}
+        if a2 != ZERO:
+            r.add(("a", a2))
+        if b2 != ZERO:
+            r.add(("b", b2))
+        return r
+
+    T = max(len(l["terms"]) for l in lanes)
+    cnt = [collections.Counter() for _ in range(T)]
+    for l in lanes:
+        for t, tm in enumerate(l["terms"]):
+            cnt[t].update(recs_of(tm))
+    cand = []
+    for li, l in enumerate(lanes):
+        cl = collections.defaultdict(list)
+        for t, tm in enumerate(l["terms"]):
+            cl[key(tm)].append(t)
+        cand += [(li, pos) for pos in cl.values() if len(pos) > 1]
+    rng = random.Random(0x5EED)
+    for _ in range(iters if cand else 0):
+        li, pos = cand[rng.randrange(len(cand))]
+        t1, t2 = rng.sample(pos, 2)
+        terms = lanes[li]["terms"]
+        r1, r2 = recs_of(terms[t1]), recs_of(terms[t2])
+        out1, out2 = r1 - r2, r2 - r1          # records that leave position t1 / t2 (and arrive at the other)
+        d = 0
+        for r in out1:
+            d += (cnt[t2][r] == 0) - (cnt[t1][r] == 1)
+        for r in out2:
+            d += (cnt[t1][r] == 0) - (cnt[t2][r] == 1)
+        if d <= 0:
+            for r in out1:
+                cnt[t1][r] -= 1
+                cnt[t2][r] += 1
+            for r in out2:
+                cnt[t2][r] -= 1
+                cnt[t1][r] += 1
+            terms[t1], terms[t2] = terms[t2], terms[t1]
+    _SHARE_CACHE[sig] = tuple(tuple(l["terms"]) for l in lanes)
+    return fetch_records(lanes)
+
+
 def encode_form(f):
     """Lin with <=2 slots and coefficients in {+-1} (or one slot with +-2) -> (s1, s2, sub, neg[, doubled]) or None"""
     items = sorted(f.items())
@@ -451,6 +538,8 @@ class Builder:
             # positions are uniformly free of negations and second operands across the 12 lanes
             enc.sort(key=lambda x: (bool(x[6]), x[1] != ZERO, x[4] != ZERO))
             lanes.append({"dst": o["dst"], "terms": enc, "alpha": o.get("alpha", 1), "beta": o.get("beta", 0), "e": o.get("e", ZERO)})
+        if SHARE_FETCHES:
+            share_operand_fetches(lanes)
         T = max(len(l["terms"]) for l in lanes)
         assert T >= 1
         # static worst case, valid for EVERY input: every LDS-resident value has |limb| <= 2^27 (+16) except raw
