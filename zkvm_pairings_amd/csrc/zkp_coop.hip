@@ -2272,11 +2272,8 @@ static void coop_resolve_table(const ZkpProgDesc& p, std::vector<uint4>& rt) {
                 lig = g0 < 5 ? wl - g0 * LIG : wv * 4 + (wl - 60);
             }
             uint32_t f1 = 0, f2 = 0;
-            // TIMING-ONLY experiment (wrong results): ZKP_EXP_LDS_SAME=1 - every lane of a group fetches lane 0's operands, so that a
-            // ds_read_b128 of the term loop has no bank conflict inside a group: what would a conflict-free LDS layout be worth?
-            static const bool lds_same = getenv("ZKP_EXP_LDS_SAME") && atoi(getenv("ZKP_EXP_LDS_SAME")) != 0;
             for (uint32_t t = 0; t < T; t++) {
-                const uint32_t w = p.tbl[off + t * LIG + (lds_same ? 0 : lig)];
+                const uint32_t w = p.tbl[off + t * LIG + lig];
                 rt[(off / LIG + t) * RL + lane] =
                     make_uint4(addr(w & 127, grp), addr((w >> 14) & 127, grp), addr((w >> 7) & 127, grp) | (addr((w >> 21) & 127, grp) << 16), 0);
                 f1 |= ((w >> 30) & 1) << t | ((w >> 31) & 1) << (12 + t);
