@@ -55,7 +55,7 @@ def main():
     a = ap.parse_args()
     fetch, dfetch = load(a.fetch_dir, "FETCH_SIZE")
     write, dwrite = load(a.write_dir, "WRITE_SIZE")
-    # five x-power chains per pass - per PART of phase C (two parts from 2^19 checks on since round 5: pass --passes explicitly then;
+    # five x-power chains per pass - per PART of phase C (two parts from 2^18 checks on since round 5: pass --passes explicitly then;
     # `bench.py --steps 1 --warmup 0 --bare` is exactly one pass)
     passes = a.passes or dfetch["k_ksq"] // 5
     assert passes and dfetch["k_ksq"] == dwrite["k_ksq"] and dfetch["k_ksq"] % (5 * passes) == 0, (dfetch, dwrite)

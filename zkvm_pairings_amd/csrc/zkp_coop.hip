@@ -28,6 +28,7 @@
 // :186-190 (+ src/fp6.rs:291-309, src/fp2.rs:278-296), conjugate :123-125; pairing semantics
 // SURVEY.md S6 (src/pairings.rs is empty upstream).
 #include "zkp_coop.hpp"
+#include "zkp_plan.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -76,6 +77,8 @@ constexpr int GROUPS = WGW == 3 ? 16 : 5;   // checks per workgroup
 constexpr int LIG = ZKP_COOP_G;        // 12 lanes per group
 constexpr int ST_SIZE = ZKP_COOP_ST_SIZE;
 constexpr int NLINES = ZKP_COOP_NLINES;
+static_assert(zkp::plan::NLINES == NLINES && zkp::plan::ST_SIZE == ST_SIZE && zkp::plan::GROUPS == (WGW == 3 ? 16 : 5),
+              "zkp_plan.hpp (the host's planning arithmetic, checked under sanitizers on the CPU) follows the generated programs");
 
 enum { OP_END = 0, OP_MULACC = 1, OP_LIN = 2, OP_GLOAD = 3, OP_GSTORE = 4, OP_LOOP = 5, OP_ENDLOOP = 6,
        OP_PLOOP = 7, OP_PENDLOOP = 8 };   // round 5: a loop over the k pairs of the launch (run-time count); its counter offsets the line loads
@@ -2200,7 +2203,7 @@ __global__ void k_fp28_op(int op, const uint64_t* a, const uint64_t* b, size_t n
 namespace zkp {
 
 struct CoopProgDev { uint32_t* hdr; uint32_t* tbl; uint4* rtbl; uint32_t nslot; uint32_t nconst; uint32_t wide; };
-constexpr int MAX_PIPES = 4;
+constexpr int MAX_PIPES = plan::MAX_PIPES;
 struct CoopDev;
 struct CoopPipe {            // one in-flight chunk: its own workspace and (for pipes > 0) its own stream
     int4* lines;  size_t lines_bytes;
@@ -2213,13 +2216,7 @@ struct CoopDev {
     CoopProgDev progs[ZKP_PROG_COUNT];
     int4* consts;
     CoopPipe pipe[MAX_PIPES];
-    int n_pipes;
-    size_t chunk;            // checks per pipeline pass (bounds the line-stream workspace: 26 KB per pair)
-    size_t super;            // checks per two-phase final exponentiation (one batched inversion for all of them)
-    bool c_single;           // phase C as one launch per large super-chunk (default) or always per chunk on the pipelines
-    size_t c_single_min;     // ... "large" = more checks than this
-    uint32_t inv_batch;      // most checks one lane inverts together (Montgomery's trick)
-    size_t inv_lanes;        // ... and the number of lanes the inversion kernel keeps busy before it batches
+    plan::Knobs kn;          // chunking / splitting knobs, clamped (zkp_plan.hpp: the arithmetic the CPU test walks under sanitizers)
     bool inv_fermat;         // a^(p-2) instead of the division-step inversion (cross-check)
     int4* big_state;         // per-check state of a whole super-chunk (7.9 KB per check)
     size_t big_state_bytes;
@@ -2236,10 +2233,11 @@ struct CoopDev {
 enum { PROF_PREP = 0, PROF_MILLER, PROF_FEXP_A, PROF_INV, PROF_KSQ, PROF_KDEC_A, PROF_KDEC_B, PROF_C_DEEP, PROF_C_PLAIN, PROF_CLASSES };
 struct ProfScope {
     CoopDev* d; hipStream_t s; hipEvent_t b = nullptr;
-    ProfScope(CoopDev* d_, hipStream_t s_, int cls) : d(d_), s(s_) {
-        if (!d->prof) return;
+    ProfScope(CoopDev* d_, hipStream_t s_, int cls) : d(d_), s(s_) {      // d may be null: a launch outside any context's profile
+        if (!d || !d->prof) return;
         hipEvent_t a = nullptr;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
+        if (hipEventCreate(&a) != hipSuccess) return;
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); b = nullptr; return; }
         (void)hipEventRecord(a, s);
         d->prof->push_back({cls, a, b});
     }
@@ -2318,32 +2316,31 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     if ((e = hipMemcpy(d->consts, ZKP_COOP_CONSTS, sizeof(ZKP_COOP_CONSTS), hipMemcpyHostToDevice)) != hipSuccess) return e;
     // chunks of a batch are processed by n_pipes independent pipelines on separate HIP streams so that the
     // tail of one kernel (and the latency-bound inversion) overlaps the next chunk's work
-    const char* ev = getenv("ZKP_COOP_STREAMS");
-    d->n_pipes = ev ? atoi(ev) : 2;
-    if (d->n_pipes < 1) d->n_pipes = 1;
-    if (d->n_pipes > MAX_PIPES) d->n_pipes = MAX_PIPES;
-    ev = getenv("ZKP_COOP_CHUNK");
-    d->chunk = ev ? (size_t)atol(ev) : ((size_t)1 << 16);   // measured best: 2 pipes x 2^16 checks
-    if (d->chunk < 320) d->chunk = 320;
-    if (d->chunk > ((size_t)1 << 20)) d->chunk = (size_t)1 << 20;   // 8 pairs x 2^20 checks x 2 lanes: every per-launch count stays in 32 bits
-    ev = getenv("ZKP_COOP_SUPER");
-    d->super = ev ? (size_t)atol(ev) : ((size_t)1 << 20);
-    if (d->super < d->chunk) d->super = d->chunk;
-    if (d->super > ((size_t)1 << 22)) d->super = (size_t)1 << 22;   // 33 GB of state; keeps every per-launch count in 32 bits
-    ev = getenv("ZKP_COOP_C_SINGLE");
-    d->c_single = ev ? atoi(ev) != 0 : true;
-    ev = getenv("ZKP_COOP_C_SINGLE_MIN");
-    d->c_single_min = ev ? (size_t)atol(ev) : d->chunk;   // measured at 2^17 / 2^18 / 2^19 checks: 37.1 / 72.9 / 142.4 ms against 37.6 / 73.6 / 142.9 with 4 chunks
-    ev = getenv("ZKP_COOP_INV_BATCH");
-    d->inv_batch = ev ? (uint32_t)atoi(ev) : 32;
-    if (d->inv_batch < 1) d->inv_batch = 1;
-    ev = getenv("ZKP_COOP_INV_LANES");
-    d->inv_lanes = ev ? (size_t)atol(ev) : ((size_t)1 << 15);   // measured best: half a wavefront per SIMD runs its chain fastest
-    if (d->inv_lanes < 1) d->inv_lanes = 1;
-    ev = getenv("ZKP_COOP_INV_FERMAT");
-    d->inv_fermat = ev && atoi(ev) != 0;
+    // every knob is read ONCE per context, here, and clamped by plan::clamp (zkp_plan.hpp): measured defaults - 2 pipes x 2^16 checks;
+    // phase C in one launch sequence above one chunk (2^17 / 2^18 / 2^19 checks: 37.1 / 72.9 / 142.4 ms against 37.6 / 73.6 / 142.9 per
+    // chunk), in two parts on the pipelines from 2^18 checks on; inversion: half a wavefront per SIMD runs its chain fastest
+    auto env_l = [](const char* name, long dflt) -> long { const char* v = getenv(name); return v ? atol(v) : dflt; };
+    plan::Knobs kn;
+    kn.n_pipes = (int)env_l("ZKP_COOP_STREAMS", kn.n_pipes);
+    kn.chunk = (size_t)env_l("ZKP_COOP_CHUNK", (long)kn.chunk);
+    kn.super = (size_t)env_l("ZKP_COOP_SUPER", (long)kn.super);
+    kn.c_single = env_l("ZKP_COOP_C_SINGLE", 1) != 0;
+    kn.inv_batch = (uint32_t)env_l("ZKP_COOP_INV_BATCH", (long)kn.inv_batch);
+    kn.inv_lanes = (size_t)env_l("ZKP_COOP_INV_LANES", (long)kn.inv_lanes);
+    // ZKP_COOP_NO_STREAM=1: groups of eight pairs joined by f12mul, the flow of rounds 1-4 (A/B baseline, cross-check);
+    // ZKP_COOP_MAX_STREAM: pairs per streamed group, 9 .. 64 (sweeps)
+    const long ms_env = env_l("ZKP_COOP_MAX_STREAM", 0);
+    kn.max_stream = env_l("ZKP_COOP_NO_STREAM", 0) != 0 ? plan::MAX_GROUP
+                    : (ms_env > (long)plan::MAX_GROUP && ms_env <= (long)plan::MAX_STREAM_LIMIT ? (size_t)ms_env : plan::MAX_STREAM);
+    kn.c_split = (int)env_l("ZKP_COOP_C_SPLIT", 0);
+    kn.c_split_min = (size_t)env_l("ZKP_COOP_C_SPLIT_MIN", (long)kn.c_split_min);
+    kn.split_min = (size_t)env_l("ZKP_COOP_SPLIT_MIN", (long)kn.split_min);
+    kn = plan::clamp(kn);
+    kn.c_single_min = (size_t)env_l("ZKP_COOP_C_SINGLE_MIN", (long)kn.chunk);
+    d->kn = kn;
+    d->inv_fermat = env_l("ZKP_COOP_INV_FERMAT", 0) != 0;
     for (int i = 0; i < MAX_PIPES; i++) d->pipe[i].owner = d;
-    for (int i = 0; i < d->n_pipes; i++) {
+    for (int i = 0; i < d->kn.n_pipes; i++) {
         if ((e = hipStreamCreateWithFlags(&d->pipe[i].stream, hipStreamNonBlocking)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&d->pipe[i].done, hipEventDisableTiming)) != hipSuccess) return e;
     }
@@ -2444,27 +2441,13 @@ static int miller_prog(size_t k, bool wire) {
     }
 }
 
-constexpr size_t MAX_GROUP = 8;   // pairs per UNROLLED Miller program (miller1..8)
+constexpr size_t MAX_GROUP = plan::MAX_GROUP;   // pairs per UNROLLED Miller program (miller1..8)
 // round 5: more pairs run through the run-time-k program (millern: a pair loop inside every iteration, ONE accumulator, the 63 squarings
-// shared by all of them) in groups of at most MAX_STREAM pairs; a check with more pairs is joined from its groups' Miller values by
+// shared by all of them) in groups of at most kn.max_stream pairs; a check with more pairs is joined from its groups' Miller values by
 // f12mul as before.  16 is the measured optimum (multi_miller_loop() of 2^20 / 2^18 pairs in checks of k, same box, ms; groups of 8 |
 // 16 | 64): k = 9: 89.4 | 85.9 | 84.5, 12: 90.6 | 87.9 | 86.7, 16: 85.6 | 87.8 | 85.9, 32: 93.1 | 86.1 | 93.9, 48: 105.0 | 93.6 | 113.1,
 // 64: 107.6 | 102.7 | 116.3, 96: 114.6 | 110.4 | 141.0 (2^18 pairs: 9: 26.5 | 23.0 | 23.3, 16: 27.0 | 25.8 | 25.8, 64: 36.0 | 33.9 | 41.3) -
 // longer groups shrink the chunks the line buffer allows (26 KB per pair) until a launch no longer fills the GPU
-constexpr size_t MAX_STREAM_LIMIT = 64;
-constexpr size_t MAX_STREAM = 16;
-// ZKP_COOP_NO_STREAM=1 (environment, read once): groups of eight pairs joined by f12mul, the flow of rounds 1-4 (A/B baseline, cross-check)
-static bool no_stream() {
-    static const bool v = getenv("ZKP_COOP_NO_STREAM") && atoi(getenv("ZKP_COOP_NO_STREAM")) != 0;
-    return v;
-}
-static size_t max_stream() {
-    // ZKP_COOP_MAX_STREAM (environment, read once): pairs per streamed group, 9 .. 64 (sweeps)
-    static const long env = getenv("ZKP_COOP_MAX_STREAM") ? atol(getenv("ZKP_COOP_MAX_STREAM")) : 0;
-    if (no_stream()) return MAX_GROUP;
-    return env > (long)MAX_GROUP && env <= (long)MAX_STREAM_LIMIT ? (size_t)env : MAX_STREAM;
-}
-static size_t group_size(size_t k) { return k <= MAX_GROUP ? k : (k < max_stream() ? k : max_stream()); }
 bool coop_supports_k(size_t k) { return k >= 1 && k <= 0xffffu; }
 
 // line stream of pairs j0 .. j0+g-1 of each of the n checks starting at base_check (k_in pairs per check)
@@ -2496,7 +2479,7 @@ static hipError_t miller_on_pipe(CoopDev* d, CoopPipe* pp, const uint64_t* g1, c
         if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, 0, (uint32_t)k, fused)) != hipSuccess) return e;
         return run_prog(d, pp, miller_prog(k, wire_out != nullptr), n, nc, (uint32_t)k, nullptr, wire_out, nullptr, nullptr);
     }
-    const size_t MS = max_stream();
+    const size_t MS = d->kn.max_stream;
     if (k <= MS) {               // one accumulator for all k pairs
         if ((e = prep(pp, g1, g2, i1, i2, base, n, (uint32_t)k, 0, (uint32_t)k, fused)) != hipSuccess) return e;
         return run_prog(d, pp, wire_out ? ZKP_PROG_MILLERN_WIRE : ZKP_PROG_MILLERN_STATE, n, nc, (uint32_t)k, nullptr, wire_out, nullptr, nullptr);
@@ -2524,19 +2507,13 @@ template <class Body>
 static hipError_t for_chunks(CoopDev* d, size_t n_total, size_t k, bool need_lines, bool need_state, hipStream_t s, Body body, size_t chunk_override = 0) {
     if (!n_total) return hipSuccess;
     hipError_t e;
-    size_t chunk = chunk_override ? chunk_override : d->chunk;
-    if (need_lines && k > 4) {   // keep the line buffer at the size four pairs per check need
-        chunk = chunk * 4 / group_size(k);
-        if (chunk < 320) chunk = 320;
-    }
-    int pipes = d->n_pipes;
-    if (n_total <= chunk || d->prof) pipes = 1;
+    const plan::Chunks pc = plan::plan_chunks(d->kn, n_total, k, need_lines, chunk_override, d->prof != nullptr);
+    const size_t chunk = pc.chunk;
+    const int pipes = pc.pipes;
     // workspace first: hipMalloc/hipFree synchronise the device, so never (re)allocate between launches
-    size_t cmax = n_total < chunk ? n_total : chunk;
     for (int i = 0; i < pipes; i++) {
-        const size_t kg = group_size(k);
-        if (need_lines && (e = ensure_buf(&d->pipe[i].lines, &d->pipe[i].lines_bytes, (size_t)NLINES * kg * 6 * cmax * 64)) != hipSuccess) return e;
-        if (need_state && (e = ensure_buf(&d->pipe[i].state, &d->pipe[i].state_bytes, (size_t)ST_SIZE * cmax * 64)) != hipSuccess) return e;
+        if (need_lines && (e = ensure_buf(&d->pipe[i].lines, &d->pipe[i].lines_bytes, plan::lines_bytes(plan::group_size(d->kn, k), pc.cmax))) != hipSuccess) return e;
+        if (need_state && (e = ensure_buf(&d->pipe[i].state, &d->pipe[i].state_bytes, plan::state_bytes(pc.cmax))) != hipSuccess) return e;
     }
     if ((e = hipEventRecord(d->ready, s)) != hipSuccess) return e;
     for (int i = 0; i < pipes; i++)
@@ -2568,8 +2545,7 @@ static hipError_t run_ksq(hipStream_t s, int4* state, uint32_t n_checks, uint32_
                           uint64_t snap_mask, CoopDev* d = nullptr) {
     if (!n_checks || !nsq) return hipSuccess;
     if (snap_mask && nsq > 64) return hipErrorInvalidValue;   // snapshot bits exist for the first 64 squarings only
-    CoopDev none{};
-    ProfScope prof(d ? d : &none, s, PROF_KSQ);
+    ProfScope prof(d, s, PROF_KSQ);
     hipLaunchKernelGGL(k_ksq, dim3((n_checks + KS_CHECKS - 1) / KS_CHECKS), dim3(64), 7 * 64 * sizeof(int4), s, state, n_checks, nc, elem_in, elem_snap, nsq, snap_mask);
     return hipGetLastError();
 }
@@ -2579,9 +2555,9 @@ static hipError_t run_ksq(hipStream_t s, int4* state, uint32_t n_checks, uint32_
 static hipError_t run_inv(CoopDev* d, hipStream_t s, int4* state, uint32_t n, uint32_t nc, uint32_t elem_n, uint32_t elem_ninv, uint32_t count) {
     const size_t total = (size_t)n * count;
     if (!total) return hipSuccess;
-    uint32_t B = (uint32_t)(total / d->inv_lanes);
-    B = B < 1 ? 1 : (B > d->inv_batch ? d->inv_batch : B);
-    const size_t lanes = (total + B - 1) / B;
+    const plan::Inv pi = plan::plan_inv(d->kn, n, count);
+    const uint32_t B = pi.batch;
+    const size_t lanes = pi.lanes;
     ProfScope prof(d, s, PROF_INV);
     hipLaunchKernelGGL(k_batch_inv, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, state, n, nc, B | (d->inv_fermat ? 0x80000000u : 0u), elem_n,
                        elem_ninv, count);
@@ -2635,9 +2611,9 @@ template <class PhaseA>
 static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_lines, hipStream_t s, uint64_t* out, uint8_t* ok, int* all_ok,
                             PhaseA phase_a) {
     hipError_t e;
-    for (size_t sb = 0; sb < n_total; sb += d->super) {
-        const size_t ns = n_total - sb < d->super ? n_total - sb : d->super;
-        if ((e = ensure_buf(&d->big_state, &d->big_state_bytes, (size_t)ST_SIZE * ns * 64)) != hipSuccess) return e;
+    for (size_t sb = 0; sb < n_total; sb += d->kn.super) {
+        const size_t ns = n_total - sb < d->kn.super ? n_total - sb : d->kn.super;
+        if ((e = ensure_buf(&d->big_state, &d->big_state_bytes, plan::state_bytes(ns))) != hipSuccess) return e;
         e = for_chunks(d, ns, k, need_lines, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
             CoopPipe v = *pp;
             v.state = d->big_state + 4 * base;
@@ -2645,23 +2621,25 @@ static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_line
         });
         if (e != hipSuccess) return e;
         if ((e = run_inv(d, s, d->big_state, (uint32_t)ns, (uint32_t)ns, ZKP_COOP_ST_N, ZKP_COOP_ST_NINV, 1)) != hipSuccess) return e;
-        // phase C needs no line buffer: one pass over a large super-chunk has no per-chunk tails (-1 % at 2^20
-        // checks); small ones do better per chunk on the two pipelines (-1 % at 2^17)
-        // experiment knob (round 4): phase C in c_split parts on the pipelines' streams, so that one part's latency-bound
-        // islands (k_batch_inv, k_kdec_a / _b) can run beside another part's step programs and squaring runs
-        // Round 5: two parts are the default from 2^18 checks on (same-box A/B, one sequence -> two parts: 2^20 234.1 / 236.0 -> 233.4 /
-        // 233.4 ms; 2^19 117.7 / 117.5 -> 115.1 / 114.8; 2^18 60.2 / 60.1 -> 59.1 / 58.6; 2^17 30.9 / 30.5 -> 30.5 / 30.6: a wash, so a
-        // rank's shard of the 8-GPU run keeps the single sequence).  ZKP_COOP_C_SPLIT=1 switches the split off.
-        static const int c_split_env = getenv("ZKP_COOP_C_SPLIT") ? atoi(getenv("ZKP_COOP_C_SPLIT")) : 0;
-        const int c_split = c_split_env > 0 ? c_split_env : (ns >= ((size_t)1 << 18) && d->n_pipes >= 2 && !d->prof ? 2 : 0);
-        if (c_split > 1 && ns > d->c_single_min) {
-            const size_t part = ((ns + c_split - 1) / c_split + 15) / 16 * 16;
+        // phase C needs no line buffer.  The plan (zkp_plan.hpp plan_phase_c): two parts on the two pipelines from 2^18 checks on (round 5,
+        // same-box A/B one sequence -> two parts: 2^20 234.1 / 236.0 -> 233.4 / 233.4 ms; 2^19 117.7 / 117.5 -> 115.1 / 114.8; 2^18 60.2 /
+        // 60.1 -> 59.1 / 58.6; 2^17 a wash), ONE launch sequence on the caller's stream below.  Round 6 measured the small and medium
+        // batches (profiles/r06/knob_sweeps.txt, the v60 traces beside it): what a 2^16 / 2^17-check batch loses against the 2^20 rate is
+        // the six k_batch_inv launches - 0.11-0.18 ms each whatever the batch, one lane's dependent chain - and the round quantisation of
+        // k_ksq (4,096 / 8,192 wavefronts on 3,072 slots).  Two parts at these sizes lose (2^16: 16.4 -> 17.1 ms) - each half-size launch
+        // has its own partial round - and two parts kept OUT of phase by events (the follower's squaring run c starts when the leader's
+        // has ended, so that one part's inversion runs beside the other's squaring run) hide the inversion but not for free: beside a
+        // squaring run it takes 0.44 instead of 0.13 ms and the run 7 % longer; 16.6 / 31.5 ms against 16.4 / 31.5.  More inversion
+        // lanes, an occupancy cap and chunks of 2^13 .. 2^15 all lose as well.  ZKP_COOP_C_SPLIT=n forces n parts (A/B, tests).
+        const plan::PhaseC pcc = plan::plan_phase_c(d->kn, ns, d->prof != nullptr);
+        if (pcc.mode == plan::C_PARTS) {
+            const size_t part = pcc.part;
             e = for_chunks(d, ns, 1, false, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
                 CoopPipe v = *pp;
                 v.state = d->big_state + 4 * base;
                 return run_fexp_c(d, &v, n, (uint32_t)ns, out ? out + 72 * (sb + base) : nullptr, ok ? ok + sb + base : nullptr, all_ok);
             }, part);
-        } else if (d->c_single && ns > d->c_single_min) {
+        } else if (pcc.mode == plan::C_SINGLE) {
             CoopPipe v = d->pipe[0];
             v.state = d->big_state;
             v.stream = s;
@@ -2710,8 +2688,17 @@ hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, c
 hipError_t coop_profile_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, size_t n, uint64_t* out_gt, float* ms, int* launches, hipStream_t s) {
     CoopDev* d = (CoopDev*)st->d_prog;
     std::vector<CoopDev::ProfEv> evs;
+    struct ProfGuard {       // d->prof points at this frame's vector: it is taken back on EVERY way out (push_back may throw)
+        CoopDev* d;
+        ~ProfGuard() { d->prof = nullptr; d->prof_phase_c = false; }
+    } guard{d};
     d->prof = &evs;
-    hipError_t e = coop_pairing(st, g1, g2, nullptr, nullptr, n, 1, out_gt, nullptr, nullptr, s);
+    hipError_t e;
+    try {
+        e = coop_pairing(st, g1, g2, nullptr, nullptr, n, 1, out_gt, nullptr, nullptr, s);
+    } catch (...) {
+        e = hipErrorOutOfMemory;
+    }
     d->prof = nullptr;
     d->prof_phase_c = false;
     const hipError_t es = hipStreamSynchronize(s);
@@ -2736,8 +2723,8 @@ hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, ui
                                   ZKP_PROG_TW_CYC_SQR};
     if (op < 0 || op > 20 || n > 0x3fffffffu) return hipErrorInvalidValue;
     hipError_t e;
-    for (size_t base = 0; base < n; base += d->chunk) {
-        const uint32_t m = (uint32_t)(n - base < d->chunk ? n - base : d->chunk);
+    for (size_t base = 0; base < n; base += d->kn.chunk) {
+        const uint32_t m = (uint32_t)(n - base < d->kn.chunk ? n - base : d->kn.chunk);
         CoopPipe v = d->pipe[0];
         v.stream = s;
         if (op >= 13) {
@@ -2760,7 +2747,7 @@ hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, ui
                 if ((e = run_prog(d, &v, one, m, m, 1, ab + 72 * base, out + 72 * base, nullptr, nullptr, 0, (uint32_t)n)) != hipSuccess) return e;
                 continue;
             }
-            if ((e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, (size_t)ST_SIZE * d->chunk * 64)) != hipSuccess) return e;
+            if ((e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, plan::state_bytes(d->kn.chunk))) != hipSuccess) return e;
             v.state = d->pipe[0].state;
             if ((e = run_prog(d, &v, pa, m, m, 1, ab + 72 * base, nullptr, nullptr, nullptr)) != hipSuccess) return e;
             if ((e = run_inv(d, s, v.state, m, m, ZKP_COOP_ST_N, ZKP_COOP_ST_NINV, 1)) != hipSuccess) return e;
@@ -2775,7 +2762,7 @@ hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, ui
             continue;
         }
         if (op == 11 && (repeat < 1 || repeat > 64)) return hipErrorInvalidValue;
-        if ((e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, (size_t)ST_SIZE * d->chunk * 64)) != hipSuccess) return e;
+        if ((e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, plan::state_bytes(d->kn.chunk))) != hipSuccess) return e;
         v.state = d->pipe[0].state;
         if (op == 12) {      // decompression alone: the record's z2..z5 are the snapshot
             if ((e = run_prog(d, &v, ZKP_PROG_TW_TO_SNAP, m, m, 1, ab + 72 * base, nullptr, nullptr, nullptr)) != hipSuccess) return e;
@@ -2802,7 +2789,7 @@ hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, hip
     static const int ids[9] = {ZKP_PROG_TIME_T1, ZKP_PROG_TIME_T3, ZKP_PROG_TIME_T3E, ZKP_PROG_TIME_T6, ZKP_PROG_TIME_T12, ZKP_PROG_TIME_LIN,
                                ZKP_PROG_TIME_CYC, ZKP_PROG_TIME_CYCSD, ZKP_PROG_TIME_FILL};
     static const int ids2[3] = {ZKP_PROG_TIME_T6S, ZKP_PROG_TIME_T12S, ZKP_PROG_TIME_T12B};   // which 12..14: one-slot / B-two-slot operand forms
-    if (which < 0 || which > 15 || !n || n > 0x7fffffffu || ((which == 10 || which == 11 || which == 15) && n > d->chunk)) return hipErrorInvalidValue;
+    if (which < 0 || which > 15 || !n || n > 0x7fffffffu || ((which == 10 || which == 11 || which == 15) && n > d->kn.chunk)) return hipErrorInvalidValue;
     hipError_t e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, (size_t)ST_SIZE * n * 64);
     if (e != hipSuccess) return e;
     if ((which == 10 || which == 11 || which == 15) && (e = ensure_buf(&d->pipe[0].lines, &d->pipe[0].lines_bytes, (size_t)NLINES * 6 * n * 64)) != hipSuccess) return e;
@@ -2860,10 +2847,10 @@ hipError_t coop_g2_valid(CoopState* st, const uint64_t* g2, const uint8_t* inf, 
             // at most 2^22 points per launch: the kernel addresses its scratch with 32-bit lane offsets and plane strides (2 lanes x 16 B
             // x 8 planes per point wrap at 2^27 points), and the scratch stays at 1 GiB whatever the batch (launches on one stream
             // run one after the other, so they may share it)
-            const size_t CH = (size_t)1 << 22;
+            const size_t CH = plan::VALID_CHUNK;
             CoopDev* d = (CoopDev*)st->d_prog;
             const size_t big = n < CH ? n : CH;
-            if ((e = ensure_buf(&d->vscratch, &d->vscratch_bytes, ((2 * big + 63) / 64) * 64 * 8 * sizeof(int4))) != hipSuccess) return e;
+            if ((e = ensure_buf(&d->vscratch, &d->vscratch_bytes, plan::vscratch_bytes(big))) != hipSuccess) return e;
             for (size_t lo = 0; lo < n; lo += CH) {
                 const size_t m = n - lo < CH ? n - lo : CH;
                 hipLaunchKernelGGL(k_g2_valid_fast3, dim3((unsigned)((2 * m + 63) / 64)), dim3(64), 3 * 4 * 64 * sizeof(int4), s, g2 + 24 * lo,

@@ -17,6 +17,7 @@
 #include "../../include/zkp_pairings.h"
 #include "zkp_field.hpp"
 #include "zkp_coop.hpp"
+#include "zkp_plan.hpp"
 
 using namespace zkp;
 
@@ -643,8 +644,8 @@ int ensure_slot(zkp_ctx* c, zkp_ctx::HostSlot* h, int which, size_t bytes) {
 // out_gt / ok / all_ok are host pointers, each optional.
 int host_sliced_impl(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t n_checks, size_t k,
                      uint64_t* out_gt, uint8_t* ok, int* all_ok) {
-    const size_t sc = c->host_slice / k ? c->host_slice / k : 1;   // checks per slice
-    const size_t nsl = (n_checks + sc - 1) / sc;
+    const zkp::plan::Slices sl = zkp::plan::plan_slices(c->host_slice, n_checks, k);
+    const size_t sc = sl.checks_per_slice, nsl = sl.n_slices;
     int rc;
     if (!c->s_in) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
@@ -888,7 +889,7 @@ int validate_on_stream(zkp_ctx* c, const void* d, size_t n_fp, hipStream_t s) {
     DevCall dc__((ctx), (stream)); \
     if (dc__.rc) return dc__.rc
 // range limits shared by the entry points: every per-launch count stays in 32 bits
-static inline bool too_many(size_t n, size_t k = 1) { return n > 0x7fffffffu || k > 0xffffu || (k && n > 0x7fffffffu / k); }
+using zkp::plan::too_many;   // zkp_plan.hpp: n <= 2^31 - 1, k <= 65535, n * k <= 2^31 - 1
 
 int zkp_pairing_batch_dev(zkp_ctx* c, const void* g1, const void* g2, const void* i1, const void* i2, size_t n, void* out, void* stream) {
     if (!c || too_many(n) || (n && (!g1 || !g2 || !out))) return ZKP_ERR_ARG;
