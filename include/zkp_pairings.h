@@ -180,6 +180,12 @@ int zkp_tower_op_batch(zkp_ctx* ctx, int op, const uint64_t* a, const uint64_t* 
 
 /* ---- device-pointer entry points (buffers already resident in HBM; asynchronous on `stream`) ---- */
 /* `stream` is a hipStream_t passed as void* (NULL = default stream).  Same formats as above. */
+/* hipGraph capture (round 6): a `_dev` call on a stream that is being captured enqueues kernel / memset nodes only - no allocation once
+ * the context's workspaces have reached the call's size (run the call once outside the capture first), no host synchronisation, and
+ * the internal pipeline streams join the capture through their fork / join events.  The hand-over of the context's workspace between
+ * calls on DIFFERENT streams (an event per context) is skipped under capture: order a replayed graph against the context's other
+ * calls yourself.  Measured (profiles/r06/v58_trace_n1.txt): launch gaps are 0.7 % of a single pairing's 3.8 ms - the kernels are
+ * bound by one wavefront's dependent instruction chain - so a graph saves nothing here; capture is supported, not needed. */
 int zkp_pairing_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1, const void* d_inf2,
                           size_t n, void* d_out_gt, void* stream);
 int zkp_multi_miller_loop_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1,
@@ -223,10 +229,9 @@ int zkp_g2_encode_batch_dev(zkp_ctx* ctx, const void* d_g2, const void* d_inf /*
  * moves only the byte strings up and the status / ok bytes down.
  * Validate first, then use (ABI version 4): only the checks whose 2k points are all valid enter the Miller loop and the final
  * exponentiation - they are listed and gathered on the device, so a check with an invalid point costs its validity tests and nothing
- * more.  For that the call reads ONE 32-bit count back from the device between the validity kernels and the pairing phase: the
- * `_dev` flavour is ordered on `stream` like every other `_dev` call, but it blocks the calling thread until the decode / is_valid
- * kernels have finished (and is therefore not capturable into a hipGraph).  ZKP_POINTS_NO_COMPACT=1 in the environment restores
- * the never-blocking flow that runs the pairing on every check. */
+ * more.  The NUMBER of listed checks never leaves the device (round 6): the pairing phase is launched for the worst case and its
+ * kernels read the count themselves, so the `_dev` flavour is asynchronous on `stream` like every other `_dev` call (no host
+ * read-back, capturable into a hipGraph once the context's workspaces have reached their size: the first call of a size allocates). */
 typedef enum {
     ZKP_POINT_OK = 0,               /* a point of the r-torsion subgroup, or a well-formed infinity */
     ZKP_POINT_NONCANONICAL = 1,     /* a coordinate >= p */

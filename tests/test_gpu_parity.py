@@ -764,6 +764,22 @@ def test_chunk_and_group_boundaries(monkeypatch):
         assert np.array_equal(ok, o.pairing_check_batch(g1[:1000], g2[:1000], 500, 2, inf1[:1000], None)) and not allok
     finally:
         e.close()
+    # round 6: a batch of at most ONE chunk is cut over the pipelines too (equal parts, a multiple of 16 checks each, when a part keeps
+    # ZKP_COOP_SPLIT_MIN checks: zkp_plan.hpp plan_chunks), and chunks are balanced - the same Gt and flags whatever the cut
+    monkeypatch.setenv("ZKP_COOP_CHUNK", "4096")
+    monkeypatch.setenv("ZKP_COOP_STREAMS", "2")
+    monkeypatch.setenv("ZKP_COOP_SUPER", "4096")
+    monkeypatch.setenv("ZKP_COOP_SPLIT_MIN", "16")
+    e = PairingEngine(0)
+    try:
+        for n in (31, 32, 33, 47, 48, 49, 1003):            # 2 x 16, 32 + 1, ..., 512 + 491
+            assert np.array_equal(e.pairing(g1[:n], g2[:n], inf1[:n], None), want[:n]), n
+        ok, allok = e.pairing_check(g1[:1000], g2[:1000], 2, inf1[:1000], None)      # 500 checks: 256 + 244
+        assert np.array_equal(ok, o.pairing_check_batch(g1[:1000], g2[:1000], 500, 2, inf1[:1000], None)) and not allok
+        ml = e.multi_miller_loop(g1[:999], g2[:999], 3, inf1[:999], None)             # 333 checks: 176 + 157
+        assert np.array_equal(ml, o.multi_miller_loop_batch(g1[:999], g2[:999], 333, 3, inf1[:999], None))
+    finally:
+        e.close()
 
 
 def test_phase_c_in_parts_gives_the_same_gt(eng):

@@ -86,6 +86,17 @@ enum { K_LINE = 0, K_STATE = 1, K_WIRE = 2, K_WIRE2 = 3 };   // K_WIRE2: wire re
 
 __device__ __constant__ const int32_t K_PBAL[NL] = {ZKP_COOP_P_BAL};
 
+// Round 6: the number of checks a launch works on may live in DEVICE memory (zkp_points_check_batch_dev: the checks whose points are all
+// valid are counted on the device and never read back).  A launch is planned on the host for the worst case - n checks from `base` of
+// the list on - and every kernel takes min(n, *cnt - base) at its entry; wavefronts behind that leave at once.  cnt == nullptr: n as given.
+struct NDev { const uint32_t* cnt; uint32_t base; };
+__device__ __forceinline__ uint32_t eff_n(uint32_t n, const NDev& nd) {
+    if (!nd.cnt) return n;
+    const uint32_t m = *nd.cnt;                 // wave-uniform: a scalar load
+    const uint32_t left = m > nd.base ? m - nd.base : 0u;
+    return left < n ? left : n;
+}
+
 struct CoopArgs {
     const uint32_t* hdr;
     const uint32_t* tbl;
@@ -105,6 +116,7 @@ struct CoopArgs {
     uint32_t nconst;          // constants the program references (prefix of the table)
     uint32_t st_off;          // added to every K_STATE element index (where a group's Miller value lands)
     uint32_t chk_off;         // K_WIRE2 loads read the wire record of check + chk_off (product tree)
+    NDev nd;                  // device-resident check count (or {nullptr, 0})
 };
 
 // ---- LDS access: quad-plane SoA, record = 4 x int4 at off, off+S, off+2S, off+3S
@@ -183,6 +195,8 @@ constexpr size_t coop_lds_bytes(int S, int SC) { return (size_t)4 * (SC + GROUPS
 template <int S, int SC>
 __global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
     extern __shared__ int4 lds[];
+    const uint32_t n_checks = eff_n(A.n_checks, A.nd);     // wave-uniform; also the stride of the line buffer (k_prep_lines takes the same)
+    if (blockIdx.x * GROUPS >= n_checks) return;          // the whole workgroup: nothing below is reached by part of it
     const int lane = threadIdx.x;        // 0 .. 64 * WGW - 1: the lane number within the workgroup
     // per-lane values, all functions of the lane number.  With the asm MULACC block (ZKP_COOP_ASM) they are re-derived at the top of
     // every step and again behind the block from an opaque copy of `lane` (ZKP_LANE_CTX): kept in registers across the block they
@@ -217,7 +231,7 @@ __global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
             lane_ok = true;                                                                             \
         }                                                                                               \
         check = blockIdx.x * GROUPS + grp;                                                              \
-        active = lane_ok && check < A.n_checks;                                                         \
+        active = lane_ok && check < n_checks;                                                           \
         gbase = SC + (lane_ok ? grp : GROUPS - 1) * SG;                                                 \
     } while (0)
     // with several wavefronts per workgroup one check's lanes sit in all of them: LDS reads and writes of a step are fenced
@@ -430,9 +444,9 @@ __global__ void __launch_bounds__(64 * WGW, ZKP_COOP_WAVES) k_coop(CoopArgs A) {
                 } else {
                     size_t rec;
 #ifdef ZKP_EXP_TRAFFIC4L   // timing-only experiment (wrong results): four checks read one line record
-                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + pair6 + idx) * A.n_checks + (check & ~3u);
+                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + pair6 + idx) * n_checks + (check & ~3u);
 #else
-                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + pair6 + idx) * A.n_checks + check;   // line buffer: this launch's checks only
+                    if (arg == K_LINE) rec = ((size_t)cursor * A.k * 6 + pair6 + idx) * n_checks + check;   // line buffer: this launch's checks only
 #endif
                     else rec = (size_t)(idx + A.st_off) * A.nc + check;
                     const int4* src = (arg == K_LINE ? A.lines : (const int4*)A.state) + rec * 4;
@@ -645,9 +659,11 @@ __device__ __forceinline__ void ksq_forms(int32_t* xr, int32_t* xi, int32_t* yr,
 // nsq compressed squarings of the Fp12 value in state elements [elem_in, elem_in + 12) (only z2..z5 are read); after
 // squaring number it + 1 where bit it of snap_mask is set, (z2..z5) go to the next snapshot area: 12 elements each from
 // elem_snap on, laid out like an Fp12 value whose z0, z1 positions are left for k_kdec_b to fill.
-__global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_in, uint32_t elem_snap,
-                                                           uint32_t nsq, uint64_t snap_mask) {
+__global__ void __launch_bounds__(64, ZKP_KSQ_WAVES) k_ksq(int4* state, uint32_t n_checks_in, uint32_t nc, uint32_t elem_in, uint32_t elem_snap,
+                                                           uint32_t nsq, uint64_t snap_mask, NDev nd) {
     extern __shared__ int4 parked[];               // 7 x 64 quads, at LDS address 0 (the asm body addresses it by lane number)
+    const uint32_t n_checks = eff_n(n_checks_in, nd);
+    if (blockIdx.x * KS_CHECKS >= n_checks) return;
     const int lane = threadIdx.x;
     const int r = lane & 3;                        // 0: A23, 1: B23, 2: A45, 3: B45
     const bool b_lane = r & 1;
@@ -1205,7 +1221,12 @@ __device__ __forceinline__ void dbl_step_cln(G2C& r, int c, S0&& sink_l0, S1&& s
 #endif
 template <bool CLN>
 __global__ void __launch_bounds__(64, ZKP_PREP_WAVES) k_prep_lines(const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2,
-                                                       uint32_t n_pairs, uint32_t k, uint32_t k_in, uint32_t j0, uint32_t nc, int4* lines) {
+                                                       uint32_t n_pairs_in, uint32_t k, uint32_t k_in, uint32_t j0, uint32_t nc_in, int4* lines, NDev nd) {
+    // nc_in checks of k pairs each (n_pairs_in = nc_in * k); with a device-resident count the launch covers the checks that exist, and
+    // their number is the stride of the line records (k_coop computes the same)
+    const uint32_t nc = eff_n(nc_in, nd);
+    const uint32_t n_pairs = nd.cnt ? nc * k : n_pairs_in;
+    if (blockIdx.x * 32u >= n_pairs) return;
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
     const int c = (int)(tid & 1);
     uint32_t pid = tid >> 1;
@@ -1963,8 +1984,9 @@ __global__ void __launch_bounds__(64, 2) k_g2_mul28(const uint64_t* base, size_t
 // then two multiplications per value on the way back.
 // A zero element (a non-invertible final_exponentiation input, the identity's compressed form) is replaced by one in the
 // chain and gets 0, as Fermat gives.
-__global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks, uint32_t nc, uint32_t Bf, uint32_t elem_n, uint32_t elem_ninv,
-                                                  uint32_t count) {
+__global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks_in, uint32_t nc, uint32_t Bf, uint32_t elem_n, uint32_t elem_ninv,
+                                                  uint32_t count, NDev nd) {
+    const uint32_t n_checks = eff_n(n_checks_in, nd);
     const uint32_t B = Bf & 0x7fffffffu;
     const bool fermat = Bf >> 31;               // cross-check path (ZKP_COOP_INV_FERMAT=1)
     const uint32_t total = n_checks * count;
@@ -2027,7 +2049,10 @@ __global__ void __launch_bounds__(64) k_batch_inv(int4* state, uint32_t n_checks
 // snapshot's z1 records and n = |D|^2 (x 4 where D = z2) in plane elem_n + snapshot; k_batch_inv inverts the planes; k_kdec_b
 // finishes: 1 / D = conj(D) / |D|^2.  The denominator D is z2 or z3 itself: since round 5 it is not stored a second time - which of
 // the two it is travels in the padding of N's record (third dword of the last quad), and k_kdec_b reads z2 and z3 anyway.
-__global__ void __launch_bounds__(64, 2) k_kdec_a(int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_snap, uint32_t count, uint32_t elem_n) {
+__global__ void __launch_bounds__(64, 2) k_kdec_a(int4* state, uint32_t n_checks_in, uint32_t nc, uint32_t elem_snap, uint32_t count, uint32_t elem_n,
+                                                  NDev nd) {
+    const uint32_t n_checks = eff_n(n_checks_in, nd);
+    if (blockIdx.x * 32u >= n_checks * count) return;
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
     const int c = (int)(tid & 1);
     uint32_t e = tid >> 1;
@@ -2077,7 +2102,10 @@ __global__ void __launch_bounds__(64, 2) k_kdec_a(int4* state, uint32_t n_checks
 #ifndef ZKP_KDEC_MERGED
 #define ZKP_KDEC_MERGED 1
 #endif
-__global__ void __launch_bounds__(64, 3) k_kdec_b(int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_snap, uint32_t count, uint32_t elem_ninv) {
+__global__ void __launch_bounds__(64, 3) k_kdec_b(int4* state, uint32_t n_checks_in, uint32_t nc, uint32_t elem_snap, uint32_t count, uint32_t elem_ninv,
+                                                  NDev nd) {
+    const uint32_t n_checks = eff_n(n_checks_in, nd);
+    if (blockIdx.x * 32u >= n_checks * count) return;
     const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
     const int c = (int)(tid & 1);
     uint32_t e = tid >> 1;
@@ -2211,6 +2239,9 @@ struct CoopPipe {            // one in-flight chunk: its own workspace and (for 
     hipStream_t stream;
     hipEvent_t done;
     CoopDev* owner;
+    // transient, set on the copy a chunk's launches are given: the check count in device memory and this chunk's offset into the list
+    // it counts (coop_pairing's n_dev argument); {nullptr, 0} otherwise
+    NDev nd;
 };
 struct CoopDev {
     CoopProgDev progs[ZKP_PROG_COUNT];
@@ -2227,6 +2258,7 @@ struct CoopDev {
     struct ProfEv { int cls; hipEvent_t a, b; };
     std::vector<ProfEv>* prof;     // null: not profiling
     bool prof_phase_c;
+    const uint32_t* n_dev;         // for the duration of one coop_pairing call: the device-resident check count (or null)
 };
 
 // kernel classes of coop_profile_pairing (include/zkp_pairings.h ZKP_PROFILE_*)
@@ -2407,6 +2439,7 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     a.nconst = d->progs[prog].nconst;
     a.st_off = st_off;
     a.chk_off = chk_off;
+    a.nd = pp->nd;
 
     static_assert(12 / WGW * coop_lds_bytes(ZKP_COOP_NSLOT, ZKP_COOP_NCONST) <= 160 * 1024 &&
                       12 / WGW * coop_lds_bytes(ZKP_COOP_WIDE_NSLOT, ZKP_COOP_WIDE_NCONST) <= 160 * 1024 &&
@@ -2461,10 +2494,10 @@ static hipError_t prep(CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, con
     static const bool no_cln = getenv("ZKP_PREP_NO_CLN") && atoi(getenv("ZKP_PREP_NO_CLN"));   // A/B knob (value cached, not the pointer)
     if (fused && !no_cln)
         hipLaunchKernelGGL(k_prep_lines<true>, dim3((2 * n_pairs + 63) / 64), dim3(64), 4 * 4 * 64 * sizeof(int4), s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
-                           i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines);
+                           i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines, pp->nd);
     else
         hipLaunchKernelGGL(k_prep_lines<false>, dim3((2 * n_pairs + 63) / 64), dim3(64), 4 * 4 * 64 * sizeof(int4), s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
-                           i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines);
+                           i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines, pp->nd);
     return hipGetLastError();
 }
 
@@ -2542,17 +2575,18 @@ hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, co
 // nsq compressed squarings of the Fp12 value in state elements [elem_in, elem_in + 12) of every check, snapshots of
 // (z2..z5) after the squarings whose bit is set in snap_mask into 12-element areas from elem_snap on
 static hipError_t run_ksq(hipStream_t s, int4* state, uint32_t n_checks, uint32_t nc, uint32_t elem_in, uint32_t elem_snap, uint32_t nsq,
-                          uint64_t snap_mask, CoopDev* d = nullptr) {
+                          uint64_t snap_mask, CoopDev* d = nullptr, NDev nd = NDev{nullptr, 0}) {
     if (!n_checks || !nsq) return hipSuccess;
     if (snap_mask && nsq > 64) return hipErrorInvalidValue;   // snapshot bits exist for the first 64 squarings only
     ProfScope prof(d, s, PROF_KSQ);
-    hipLaunchKernelGGL(k_ksq, dim3((n_checks + KS_CHECKS - 1) / KS_CHECKS), dim3(64), 7 * 64 * sizeof(int4), s, state, n_checks, nc, elem_in, elem_snap, nsq, snap_mask);
+    hipLaunchKernelGGL(k_ksq, dim3((n_checks + KS_CHECKS - 1) / KS_CHECKS), dim3(64), 7 * 64 * sizeof(int4), s, state, n_checks, nc, elem_in, elem_snap, nsq, snap_mask, nd);
     return hipGetLastError();
 }
 
 // batched inversion of `count` planes of n per-check values (k_batch_inv): few lanes with long batches, because the kernel
 // is bound by the latency of one lane's chain (610 + 3 B multiplications)
-static hipError_t run_inv(CoopDev* d, hipStream_t s, int4* state, uint32_t n, uint32_t nc, uint32_t elem_n, uint32_t elem_ninv, uint32_t count) {
+static hipError_t run_inv(CoopDev* d, hipStream_t s, int4* state, uint32_t n, uint32_t nc, uint32_t elem_n, uint32_t elem_ninv, uint32_t count,
+                          NDev nd = NDev{nullptr, 0}) {
     const size_t total = (size_t)n * count;
     if (!total) return hipSuccess;
     const plan::Inv pi = plan::plan_inv(d->kn, n, count);
@@ -2560,7 +2594,7 @@ static hipError_t run_inv(CoopDev* d, hipStream_t s, int4* state, uint32_t n, ui
     const size_t lanes = pi.lanes;
     ProfScope prof(d, s, PROF_INV);
     hipLaunchKernelGGL(k_batch_inv, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, state, n, nc, B | (d->inv_fermat ? 0x80000000u : 0u), elem_n,
-                       elem_ninv, count);
+                       elem_ninv, count, nd);
     return hipGetLastError();
 }
 
@@ -2577,20 +2611,20 @@ static hipError_t run_fexp_c(CoopDev* d, CoopPipe* pp, uint32_t n, uint32_t nc, 
                 e = run_prog(d, pp, (int)ps.a, n, nc, 1, nullptr, wire_out, ok, all_ok);
                 break;
             case ZKP_PLAN_KSQ:
-                e = run_ksq(pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, ps.mask, d);
+                e = run_ksq(pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, ps.mask, d, pp->nd);
                 break;
             case ZKP_PLAN_KDEC_A: {
                 ProfScope prof(d, pp->stream, PROF_KDEC_A);
-                hipLaunchKernelGGL(k_kdec_a, dim3((unsigned)((2 * (size_t)n * ps.b + 63) / 64)), dim3(64), 0, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c);
+                hipLaunchKernelGGL(k_kdec_a, dim3((unsigned)((2 * (size_t)n * ps.b + 63) / 64)), dim3(64), 0, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, pp->nd);
                 e = hipGetLastError();
                 break;
             }
             case ZKP_PLAN_INV:
-                e = run_inv(d, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c);
+                e = run_inv(d, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, pp->nd);
                 break;
             case ZKP_PLAN_KDEC_B: {
                 ProfScope prof(d, pp->stream, PROF_KDEC_B);
-                hipLaunchKernelGGL(k_kdec_b, dim3((unsigned)((2 * (size_t)n * ps.b + 63) / 64)), dim3(64), 0, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c);
+                hipLaunchKernelGGL(k_kdec_b, dim3((unsigned)((2 * (size_t)n * ps.b + 63) / 64)), dim3(64), 0, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, pp->nd);
                 e = hipGetLastError();
                 break;
             }
@@ -2617,10 +2651,11 @@ static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_line
         e = for_chunks(d, ns, k, need_lines, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
             CoopPipe v = *pp;
             v.state = d->big_state + 4 * base;
+            v.nd = NDev{d->n_dev, (uint32_t)(sb + base)};
             return phase_a(&v, sb + base, n, (uint32_t)ns);
         });
         if (e != hipSuccess) return e;
-        if ((e = run_inv(d, s, d->big_state, (uint32_t)ns, (uint32_t)ns, ZKP_COOP_ST_N, ZKP_COOP_ST_NINV, 1)) != hipSuccess) return e;
+        if ((e = run_inv(d, s, d->big_state, (uint32_t)ns, (uint32_t)ns, ZKP_COOP_ST_N, ZKP_COOP_ST_NINV, 1, NDev{d->n_dev, (uint32_t)sb})) != hipSuccess) return e;
         // phase C needs no line buffer.  The plan (zkp_plan.hpp plan_phase_c): two parts on the two pipelines from 2^18 checks on (round 5,
         // same-box A/B one sequence -> two parts: 2^20 234.1 / 236.0 -> 233.4 / 233.4 ms; 2^19 117.7 / 117.5 -> 115.1 / 114.8; 2^18 60.2 /
         // 60.1 -> 59.1 / 58.6; 2^17 a wash), ONE launch sequence on the caller's stream below.  Round 6 measured the small and medium
@@ -2637,17 +2672,20 @@ static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_line
             e = for_chunks(d, ns, 1, false, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
                 CoopPipe v = *pp;
                 v.state = d->big_state + 4 * base;
+                v.nd = NDev{d->n_dev, (uint32_t)(sb + base)};
                 return run_fexp_c(d, &v, n, (uint32_t)ns, out ? out + 72 * (sb + base) : nullptr, ok ? ok + sb + base : nullptr, all_ok);
             }, part);
         } else if (pcc.mode == plan::C_SINGLE) {
             CoopPipe v = d->pipe[0];
             v.state = d->big_state;
             v.stream = s;
+            v.nd = NDev{d->n_dev, (uint32_t)sb};
             e = run_fexp_c(d, &v, (uint32_t)ns, (uint32_t)ns, out ? out + 72 * sb : nullptr, ok ? ok + sb : nullptr, all_ok);
         } else {
             e = for_chunks(d, ns, 1, false, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
                 CoopPipe v = *pp;
                 v.state = d->big_state + 4 * base;
+                v.nd = NDev{d->n_dev, (uint32_t)(sb + base)};
                 return run_fexp_c(d, &v, n, (uint32_t)ns, out ? out + 72 * (sb + base) : nullptr, ok ? ok + sb + base : nullptr, all_ok);
             });
         }
@@ -2673,14 +2711,19 @@ hipError_t coop_fp12_mul_pairs(CoopState* st, uint64_t* buf, size_t m, size_t h,
 }
 
 hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
-                        uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s) {
+                        uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s, const uint32_t* n_dev) {
     CoopDev* d = (CoopDev*)st->d_prog;
     if (!coop_supports_k(k)) return hipErrorNotSupported;
-    return two_phase(d, n_checks, k, true, s, out_gt, ok, all_ok, [&](CoopPipe* pp, size_t base, uint32_t n, uint32_t nc) -> hipError_t {
+    // n_dev (device memory, may be null): only the first min(n_checks, *n_dev) checks exist - the launches are planned for n_checks and
+    // size themselves on the device (NDev); nothing is read back
+    d->n_dev = n_dev;
+    const hipError_t e2 = two_phase(d, n_checks, k, true, s, out_gt, ok, all_ok, [&](CoopPipe* pp, size_t base, uint32_t n, uint32_t nc) -> hipError_t {
         hipError_t e = miller_on_pipe(d, pp, g1, g2, i1, i2, base, n, nc, k, nullptr, true);
         if (e != hipSuccess) return e;
         return run_prog(d, pp, ZKP_PROG_FEXP_A_STATE, n, nc, 1, nullptr, nullptr, nullptr, nullptr);
     });
+    d->n_dev = nullptr;
+    return e2;
 }
 
 // one pass of the fused pairing with every launch bracketed by events (one pipeline: no two kernels overlap); ms[c] = the
@@ -2695,7 +2738,7 @@ hipError_t coop_profile_pairing(CoopState* st, const uint64_t* g1, const uint64_
     d->prof = &evs;
     hipError_t e;
     try {
-        e = coop_pairing(st, g1, g2, nullptr, nullptr, n, 1, out_gt, nullptr, nullptr, s);
+        e = coop_pairing(st, g1, g2, nullptr, nullptr, n, 1, out_gt, nullptr, nullptr, s, nullptr);
     } catch (...) {
         e = hipErrorOutOfMemory;
     }
@@ -2770,10 +2813,10 @@ hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, ui
             if ((e = run_prog(d, &v, ZKP_PROG_TW_TO_STATE, m, m, 1, ab + 72 * base, nullptr, nullptr, nullptr)) != hipSuccess) return e;
             if ((e = run_ksq(s, v.state, m, m, 0, ZKP_COOP_ST_SNAP, repeat, 1ull << (repeat - 1))) != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_kdec_a, dim3((2 * m + 63) / 64), dim3(64), 0, s, v.state, m, m, (uint32_t)ZKP_COOP_ST_SNAP, 1u, (uint32_t)ZKP_COOP_ST_KN);
+        hipLaunchKernelGGL(k_kdec_a, dim3((2 * m + 63) / 64), dim3(64), 0, s, v.state, m, m, (uint32_t)ZKP_COOP_ST_SNAP, 1u, (uint32_t)ZKP_COOP_ST_KN, NDev{nullptr, 0});
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = run_inv(d, s, v.state, m, m, ZKP_COOP_ST_KN, ZKP_COOP_ST_KNINV, 1)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_kdec_b, dim3((2 * m + 63) / 64), dim3(64), 0, s, v.state, m, m, (uint32_t)ZKP_COOP_ST_SNAP, 1u, (uint32_t)ZKP_COOP_ST_KNINV);
+        hipLaunchKernelGGL(k_kdec_b, dim3((2 * m + 63) / 64), dim3(64), 0, s, v.state, m, m, (uint32_t)ZKP_COOP_ST_SNAP, 1u, (uint32_t)ZKP_COOP_ST_KNINV, NDev{nullptr, 0});
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = run_prog(d, &v, ZKP_PROG_TW_FROM_SNAP, m, m, 1, nullptr, out + 72 * base, nullptr, nullptr)) != hipSuccess) return e;
     }

@@ -38,8 +38,9 @@ hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, co
 hipError_t coop_final_exp(CoopState* st, const uint64_t* f, size_t n, uint64_t* out, uint8_t* ok, int* all_ok, hipStream_t s);
 // one level of the Fp12 product tree, in place on wire records: buf[c] <- buf[c] * buf[c + h] for c < m
 hipError_t coop_fp12_mul_pairs(CoopState* st, uint64_t* buf, size_t m, size_t h, hipStream_t s);
+// n_dev (device pointer, may be null): the number of checks that exist, <= n_checks, read by the kernels themselves (never by the host)
 hipError_t coop_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks,
-                        size_t k, uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s);
+                        size_t k, uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s, const uint32_t* n_dev = nullptr);
 
 // measurement: one pass of the fused pairing, ms / launches per kernel class (ZKP_PROFILE_CLASSES of them, include/zkp_pairings.h)
 hipError_t coop_profile_pairing(CoopState* st, const uint64_t* g1, const uint64_t* g2, size_t n, uint64_t* out_gt, float* ms, int* launches, hipStream_t s);

@@ -403,17 +403,24 @@ __global__ void k_checks_compact(const uint8_t* st1, const uint8_t* st2, size_t 
     base = __shfl(base, __ffsll((long long)m) - 1);
     if (good) idx[base + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)c;
 }
-// out[j * words + w] = in[idx[j] * words + w]: `words` 64-bit words (or bytes: T = uint8_t) per check
+// out[j * words + w] = in[idx[j] * words + w]: `words` 64-bit words (or bytes: T = uint8_t) per check.  Round 6: the number of listed
+// checks is read from DEVICE memory (*count <= n_max; the grid covers n_max checks) - the host never learns it
 template <class T>
-__global__ void k_gather_checks(const T* in, const uint32_t* idx, size_t m, size_t words, T* out) {
+__global__ void k_gather_checks(const T* in, const uint32_t* idx, const uint32_t* count, size_t n_max, size_t words, T* out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t m = *count < n_max ? *count : n_max;
     if (i >= m * words) return;
     const size_t j = i / words, w = i - j * words;
     out[i] = in[(size_t)idx[j] * words + w];
 }
-__global__ void k_scatter_ok(const uint8_t* okc, const uint32_t* idx, size_t m, uint8_t* ok) {
+__global__ void k_scatter_ok(const uint8_t* okc, const uint32_t* idx, const uint32_t* count, size_t n_max, uint8_t* ok) {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t m = *count < n_max ? *count : n_max;
     if (j < m) ok[idx[j]] = okc[j];
+}
+// the AND over all checks is 0 as soon as one check failed its validity tests, whatever the pairings of the others say
+__global__ void k_flag_if_fewer(int* all_ok, const uint32_t* count, uint32_t n_checks) {
+    if (*count < n_checks) *all_ok = 0;
 }
 
 // every 6-limb element of a wire buffer must be < p
@@ -454,7 +461,6 @@ struct zkp_ctx {
     // zkp_points_check_batch: decoded points, infinity flags, decode / is_valid / merged status bytes, ok bytes (grow-only)
     void* pc[18] = {};
     size_t pc_cap[18] = {};
-    uint32_t* h_count = nullptr;   // page-locked word: the number of valid checks comes back through it
     // one-rank-per-GPU communicator (zkp_comm_init_rank); null until then
     ncclComm_t comm = nullptr;
     int comm_nranks = 0, comm_rank = 0;
@@ -529,15 +535,17 @@ int final_exp_dev(zkp_ctx* c, const uint64_t* f, size_t n, uint64_t* out, hipStr
     HIPCHK(c, hipGetLastError());
     return ZKP_OK;
 }
+// n_dev (device pointer, cooperative family only): the number of checks that really exist (<= n_checks) - see zkp::coop_pairing
 int pairing_dev(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* i1, const uint8_t* i2, size_t n_checks, size_t k,
-                uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s, bool reset_flag = true) {
+                uint64_t* out_gt, uint8_t* ok, int* all_ok, hipStream_t s, bool reset_flag = true, const uint32_t* n_dev = nullptr) {
     if (all_ok && reset_flag) {
         hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, all_ok, 1);
         HIPCHK(c, hipGetLastError());
     }
     if (n_checks == 0) return ZKP_OK;
     if (zkp::coop_selected(&c->coop, c->kernel) && zkp::coop_supports_k(k))
-        return coop_rc(c, "coop_pairing", zkp::coop_pairing(&c->coop, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok, s));
+        return coop_rc(c, "coop_pairing", zkp::coop_pairing(&c->coop, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok, s, n_dev));
+    if (n_dev) { c->err = "pairing_dev: a device-resident count needs the cooperative kernel family"; return ZKP_ERR_ARG; }
     hipLaunchKernelGGL(k_pairing, dim3(grid_for(n_checks, TPB)), dim3(TPB), 0, s, g1, g2, i1, i2, n_checks, k, out_gt, ok, all_ok);
     HIPCHK(c, hipGetLastError());
     return ZKP_OK;
@@ -824,7 +832,6 @@ void zkp_free(zkp_ctx* c) {
         if (c->buf[i]) (void)hipFree(c->buf[i]);
     for (int i = 0; i < 18; i++)
         if (c->pc[i]) (void)hipFree(c->pc[i]);
-    if (c->h_count) (void)hipHostFree(c->h_count);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->prod) (void)hipFree(c->prod);
     for (int i = 0; i < 2; i++) {
@@ -865,16 +872,22 @@ namespace {
 // The workspace inside a ctx (line buffers, per-check state, product tree, flags) is shared by every call: a *_dev call
 // first makes its stream wait for the previous call's last use of the workspace - which may have been queued on ANOTHER
 // stream - and leaves an event behind for the next one.  Calls on one stream order themselves anyway.
+// A stream that is being CAPTURED into a hipGraph (round 6) takes no part in that hand-over: an event recorded outside the capture may
+// not be waited for inside it, and one recorded inside would poison the next ordinary call.  Whoever replays the graph orders it
+// against the context's other calls himself (one stream, or his own events) - include/zkp_pairings.h, "hipGraph capture".
 struct DevCall {
     zkp_ctx* c;
     hipStream_t s;
     int rc;
-    DevCall(zkp_ctx* ctx, void* stream) : c(ctx), s((hipStream_t)stream), rc(ZKP_OK) {
+    bool capturing;
+    DevCall(zkp_ctx* ctx, void* stream) : c(ctx), s((hipStream_t)stream), rc(ZKP_OK), capturing(false) {
         hipError_t e = hipSetDevice(c->device);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s, c->ws_busy, 0);
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (e == hipSuccess && s && hipStreamIsCapturing(s, &cs) == hipSuccess) capturing = cs == hipStreamCaptureStatusActive;
+        if (e == hipSuccess && !capturing) e = hipStreamWaitEvent(s, c->ws_busy, 0);
         if (e != hipSuccess) { c->err = std::string("DevCall: ") + hipGetErrorString(e); rc = ZKP_ERR_HIP; }
     }
-    ~DevCall() { if (rc == ZKP_OK) (void)hipEventRecord(c->ws_busy, s); }
+    ~DevCall() { if (rc == ZKP_OK && !capturing) (void)hipEventRecord(c->ws_busy, s); }
 };
 // validation mode on the device-pointer entry points: a range check of the inputs on the caller's stream that ORs into a
 // sticky word (no host synchronisation); zkp_take_validation_status_dev reads and clears it
@@ -1032,19 +1045,27 @@ static int ensure_pc(zkp_ctx* c, int slot, size_t bytes) {
     return ZKP_OK;
 }
 enum { PC_G1 = 0, PC_G2, PC_INF1, PC_INF2, PC_DEC, PC_VAL, PC_ST1, PC_ST2, PC_OK, PC_BYTES, PC_IDX, PC_CNT, PC_CG1, PC_CG2, PC_CINF1, PC_CINF2, PC_COK };
-// ZKP_POINTS_NO_COMPACT=1 (environment, read once): the round-4 flow - the fused pairing runs on every check, valid or not, and the call
-// never waits on the host (the A/B baseline and the cross-check of the compacted flow)
-static bool points_no_compact() {
-    static const bool v = getenv("ZKP_POINTS_NO_COMPACT") && atoi(getenv("ZKP_POINTS_NO_COMPACT")) != 0;
-    return v;
-}
+// Validate first, then use (reference src/g1.rs:49-62, src/g2.rs:57-69: is_valid before anything is done with a point): the checks whose
+// points are all valid are listed on the device (wave-aggregated compaction), gathered next to each other, and only those enter the
+// Miller loop and the final exponentiation - a check with an invalid point costs its validity tests and nothing else.  Round 6: the
+// NUMBER of listed checks stays in device memory.  The pairing phase is planned for the worst case (every check valid) and its kernels
+// read the count themselves (zkp::coop_pairing's n_dev: wavefronts behind the count leave at once), so the call never waits on the
+// host: asynchronous on `s` like every other *_dev entry point, and capturable into a hipGraph once its workspaces exist.  (Round 5 read
+// the count back - 4 bytes, one hipStreamSynchronize - to size the grids on the host.)  The thread family has no such kernels: it
+// runs the fused pairing on every check and fails the invalid ones afterwards (k_checks_merge), as round 4 did.
 static int points_check_dev(zkp_ctx* c, const void* b1, const void* b2, size_t n_checks, size_t k, void* st1, void* st2, void* ok, int* all_ok,
                             hipStream_t s) {
     const size_t np = n_checks * k;
+    const bool compact = n_checks && k && zkp::coop_selected(&c->coop, c->kernel) && zkp::coop_supports_k(k);
     int rc;
+    // every workspace first (an allocation synchronises the device): nothing below this block allocates
     if ((rc = ensure_pc(c, PC_G1, np * 96 + 8)) || (rc = ensure_pc(c, PC_G2, np * 192 + 8)) || (rc = ensure_pc(c, PC_INF1, np + 8)) ||
         (rc = ensure_pc(c, PC_INF2, np + 8)) || (rc = ensure_pc(c, PC_DEC, 2 * np + 8)) || (rc = ensure_pc(c, PC_VAL, 2 * np + 8)) ||
         (rc = ensure_pc(c, PC_ST1, np + 8)) || (rc = ensure_pc(c, PC_ST2, np + 8)) || (rc = ensure_pc(c, PC_OK, n_checks + 8)))
+        return rc;
+    if (compact && ((rc = ensure_pc(c, PC_IDX, n_checks * 4 + 8)) || (rc = ensure_pc(c, PC_CNT, 8)) || (rc = ensure_pc(c, PC_CG1, np * 96 + 8)) ||
+                    (rc = ensure_pc(c, PC_CG2, np * 192 + 8)) || (rc = ensure_pc(c, PC_CINF1, np + 8)) || (rc = ensure_pc(c, PC_CINF2, np + 8)) ||
+                    (rc = ensure_pc(c, PC_COK, n_checks + 8))))
         return rc;
     uint8_t* dec1 = (uint8_t*)c->pc[PC_DEC];
     uint8_t* dec2 = dec1 + np;
@@ -1062,55 +1083,32 @@ static int points_check_dev(zkp_ctx* c, const void* b1, const void* b2, size_t n
         hipLaunchKernelGGL(k_points_merge, dim3(grid_for(np, 256)), dim3(256), 0, s, dec2, val2, (uint8_t*)c->pc[PC_INF2], np, s2);
         HIPCHK(c, hipGetLastError());
     }
-    // Validate first, then use (reference src/g1.rs:49-62: is_valid before anything is done with a point): the checks whose points are
-    // all valid are listed, their number comes back to the host (one 4-byte read-back: the call waits for the decode / is_valid
-    // kernels here - the grids of the pairing phase depend on it), and only those checks enter the Miller loop and the final
-    // exponentiation.  A check with an invalid point costs its validity tests and nothing else.
-    size_t m = n_checks;
-    const bool compact = n_checks && k && !points_no_compact();
-    if (compact) {
-        if ((rc = ensure_pc(c, PC_IDX, n_checks * 4 + 8)) || (rc = ensure_pc(c, PC_CNT, 8))) return rc;
-        if (!c->h_count) HIPCHK(c, hipHostMalloc((void**)&c->h_count, 8, hipHostMallocDefault));
-        HIPCHK(c, hipMemsetAsync(c->pc[PC_CNT], 0, 4, s));
-        hipLaunchKernelGGL(k_checks_compact, dim3(grid_for(n_checks, 256)), dim3(256), 0, s, s1, s2, n_checks, k, (uint32_t*)c->pc[PC_IDX], (uint32_t*)c->pc[PC_CNT], okb);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(c->h_count, c->pc[PC_CNT], 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        m = *c->h_count;
-        if (m > n_checks) { c->err = "zkp_points_check: the count of valid checks is out of range"; return ZKP_ERR_HIP; }
-    }
-    if (m == n_checks) {
+    if (!compact) {
         if ((rc = pairing_dev(c, (const uint64_t*)c->pc[PC_G1], (const uint64_t*)c->pc[PC_G2], (const uint8_t*)c->pc[PC_INF1], (const uint8_t*)c->pc[PC_INF2],
                               n_checks, k, nullptr, okb, all_ok, s)))
             return rc;
-        if (n_checks && k && !compact) {
+        if (n_checks && k) {
             hipLaunchKernelGGL(k_checks_merge, dim3(grid_for(n_checks, 256)), dim3(256), 0, s, s1, s2, n_checks, k, okb, all_ok);
             HIPCHK(c, hipGetLastError());
         }
         return ZKP_OK;
     }
-    // some checks failed their validity tests (their ok bytes are 0 already): gather the others, run them, put their ok bytes back
-    const size_t mp = m * k;
-    if (m) {
-        if ((rc = ensure_pc(c, PC_CG1, mp * 96 + 8)) || (rc = ensure_pc(c, PC_CG2, mp * 192 + 8)) || (rc = ensure_pc(c, PC_CINF1, mp + 8)) ||
-            (rc = ensure_pc(c, PC_CINF2, mp + 8)) || (rc = ensure_pc(c, PC_COK, m + 8)))
-            return rc;
-        const uint32_t* idx = (const uint32_t*)c->pc[PC_IDX];
-        hipLaunchKernelGGL(k_gather_checks<uint64_t>, dim3(grid_for(mp * 12, 256)), dim3(256), 0, s, (const uint64_t*)c->pc[PC_G1], idx, m, k * 12, (uint64_t*)c->pc[PC_CG1]);
-        hipLaunchKernelGGL(k_gather_checks<uint64_t>, dim3(grid_for(mp * 24, 256)), dim3(256), 0, s, (const uint64_t*)c->pc[PC_G2], idx, m, k * 24, (uint64_t*)c->pc[PC_CG2]);
-        hipLaunchKernelGGL(k_gather_checks<uint8_t>, dim3(grid_for(mp, 256)), dim3(256), 0, s, (const uint8_t*)c->pc[PC_INF1], idx, m, k, (uint8_t*)c->pc[PC_CINF1]);
-        hipLaunchKernelGGL(k_gather_checks<uint8_t>, dim3(grid_for(mp, 256)), dim3(256), 0, s, (const uint8_t*)c->pc[PC_INF2], idx, m, k, (uint8_t*)c->pc[PC_CINF2]);
-        HIPCHK(c, hipGetLastError());
-        if ((rc = pairing_dev(c, (const uint64_t*)c->pc[PC_CG1], (const uint64_t*)c->pc[PC_CG2], (const uint8_t*)c->pc[PC_CINF1], (const uint8_t*)c->pc[PC_CINF2],
-                              m, k, nullptr, (uint8_t*)c->pc[PC_COK], nullptr, s)))
-            return rc;
-        hipLaunchKernelGGL(k_scatter_ok, dim3(grid_for(m, 256)), dim3(256), 0, s, (const uint8_t*)c->pc[PC_COK], idx, m, okb);
-        HIPCHK(c, hipGetLastError());
-    }
-    if (all_ok) {      // at least one check failed its validity tests: the AND is 0 whatever the pairings say
-        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, all_ok, 0);
-        HIPCHK(c, hipGetLastError());
-    }
+    uint32_t* const idx = (uint32_t*)c->pc[PC_IDX];
+    uint32_t* const cnt = (uint32_t*)c->pc[PC_CNT];
+    HIPCHK(c, hipMemsetAsync(cnt, 0, 4, s));
+    hipLaunchKernelGGL(k_checks_compact, dim3(grid_for(n_checks, 256)), dim3(256), 0, s, s1, s2, n_checks, k, idx, cnt, okb);
+    hipLaunchKernelGGL(k_gather_checks<uint64_t>, dim3(grid_for(np * 12, 256)), dim3(256), 0, s, (const uint64_t*)c->pc[PC_G1], idx, cnt, n_checks, k * 12, (uint64_t*)c->pc[PC_CG1]);
+    hipLaunchKernelGGL(k_gather_checks<uint64_t>, dim3(grid_for(np * 24, 256)), dim3(256), 0, s, (const uint64_t*)c->pc[PC_G2], idx, cnt, n_checks, k * 24, (uint64_t*)c->pc[PC_CG2]);
+    hipLaunchKernelGGL(k_gather_checks<uint8_t>, dim3(grid_for(np, 256)), dim3(256), 0, s, (const uint8_t*)c->pc[PC_INF1], idx, cnt, n_checks, k, (uint8_t*)c->pc[PC_CINF1]);
+    hipLaunchKernelGGL(k_gather_checks<uint8_t>, dim3(grid_for(np, 256)), dim3(256), 0, s, (const uint8_t*)c->pc[PC_INF2], idx, cnt, n_checks, k, (uint8_t*)c->pc[PC_CINF2]);
+    HIPCHK(c, hipGetLastError());
+    // the listed checks (their points are all valid): fused pairing, ok bytes in list order, the AND flag over them
+    if ((rc = pairing_dev(c, (const uint64_t*)c->pc[PC_CG1], (const uint64_t*)c->pc[PC_CG2], (const uint8_t*)c->pc[PC_CINF1], (const uint8_t*)c->pc[PC_CINF2],
+                          n_checks, k, nullptr, (uint8_t*)c->pc[PC_COK], all_ok, s, true, cnt)))
+        return rc;
+    hipLaunchKernelGGL(k_scatter_ok, dim3(grid_for(n_checks, 256)), dim3(256), 0, s, (const uint8_t*)c->pc[PC_COK], idx, cnt, n_checks, okb);
+    if (all_ok) hipLaunchKernelGGL(k_flag_if_fewer, dim3(1), dim3(1), 0, s, all_ok, cnt, (uint32_t)n_checks);
+    HIPCHK(c, hipGetLastError());
     return ZKP_OK;
 }
 int zkp_points_check_batch_dev(zkp_ctx* c, const void* g1_bytes, const void* g2_bytes, size_t n_checks, size_t k, void* st1, void* st2, void* ok,
