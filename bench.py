@@ -81,33 +81,36 @@ def launch_ranks(n_ranks, argv):
     """the launcher half of `python bench.py --gpus N` (N > 1, no WORLD_SIZE): run the N ranks under torch.distributed.run as a child
     process (never an exec: nothing here has touched the GPU, and nothing will), relay rank 0's JSON line to stdout - everything else
     the ranks print goes to stderr - and return the child's exit code (3 if no line came back from a child that claimed success)"""
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
-    env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    sys.stderr.write("bench.py: launching %d ranks: %s\n" % (n_ranks, " ".join(cmd)))
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    line = None
-    for out in proc.stdout:
-        txt = out.strip()
-        is_line = False
-        if txt.startswith("{") and '"metric"' in txt:
-            try:
-                json.loads(txt)
-                is_line = True
-            except ValueError:
-                pass
-        if is_line:
-            line = txt
-        else:
-            sys.stderr.write(out)
-    rc = proc.wait()
+    # --standalone: torchrun's own rendezvous on 127.0.0.1 binds a free port ITSELF (round 6: no port is probed here and closed again before
+    # torchrun binds it - a race on a busy box).  A launch that dies before any rank reports (a bind / rendezvous failure) is started once
+    # more, as a fresh child process ("dies before any rank reports" = non-zero code within 30 s and no result line).
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           os.path.abspath(__file__)] + list(argv)
+    rc, line = 1, None
+    for attempt in (1, 2):
+        sys.stderr.write("bench.py: launching %d ranks (attempt %d): %s\n" % (n_ranks, attempt, " ".join(cmd)))
+        t_start = time.time()
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+        line = None
+        for out in proc.stdout:
+            txt = out.strip()
+            is_line = False
+            if txt.startswith("{") and '"metric"' in txt:
+                try:
+                    json.loads(txt)
+                    is_line = True
+                except ValueError:
+                    pass
+            if is_line:
+                line = txt
+            else:
+                sys.stderr.write(out)
+        rc = proc.wait()
+        if rc == 0 or line is not None or time.time() - t_start > 30:
+            break
     if line is not None:
         print(line, flush=True)
     elif rc == 0:
@@ -127,6 +130,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=16384, help="pairs of the oracle leg (parity sample + all-cores baseline)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores oracle leg (default: usable cores, at most 16 per GPU of the job)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep (n = 1 .. 2^18, k = 1 and 3; outside the timed region)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-4 / config-5 / host-API legs (they run outside the timed region)")
     ap.add_argument("--bare", action="store_true", help="profiling runs: only warm-up + timed passes reach the GPU (no phase timing, clock "
                                                         "probe or oracle leg), so that a rocprofv3 counter run holds exactly those passes")
@@ -204,7 +208,21 @@ def main():
         uid0 = [z.PairingEngine.comm_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(uid0, src=0)
-        eng.comm_init_rank(world, rank, uid0[0])
+        init_ok = 1
+        try:
+            eng.comm_init_rank(world, rank, uid0[0])
+        except z.ZkpError as ex:
+            init_ok = 0
+            sys.stderr.write("bench.py: rank %d: zkp_comm_init_rank failed: %r\n" % (rank, ex))
+        if world > 1:
+            # a rank whose init failed locally (after the bootstrap) is not a member any more and its peers cannot know: agree over the
+            # control plane BEFORE anyone enters a collective (include/zkp_pairings.h, zkp_comm_init_rank)
+            agreed = torch.tensor([init_ok], dtype=torch.int32)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            init_ok = int(agreed.item())
+        if not init_ok:
+            sys.stderr.write("bench.py: rank %d: the library communicator is not complete on every rank - leaving\n" % rank)
+            sys.exit(4)
 
         def step():
             # ONE C-ABI call per rank: Gt + ok bytes of the rank's shard, then ncclAllReduce(count 1, int32, MIN) of the AND flag
@@ -339,15 +357,7 @@ def main():
             return e0.elapsed_time(e1) / reps, r
 
         # the two phases on their own (the *_dev calls fork and join on torch's current stream, so its events see them)
-        ml_ms = fe_ms = sustained_ghz = prep_ms = mil_ms = None
-        if not args.bare and args.kernel in ("auto", "coop"):
-            # the two kernels of the Miller phase on their own, on one 2^16-check chunk (what a launch of the pipeline covers)
-            nk = min(n, 1 << 16)
-            try:
-                prep_ms = eng.time_coop_step(10, nk) * n / nk
-                mil_ms = eng.time_coop_step(11, nk) * n / nk
-            except z.ZkpError:      # ZKP_COOP_CHUNK below 2^16 (env experiments): the split is left out, the line still prints
-                prep_ms = mil_ms = None
+        ml_ms = fe_ms = sustained_ghz = None
         if not args.bare:
             ml_ms, ml = timed_ms(lambda: eng.multi_miller_loop(g1, g2, 1))
             fe_ms, _ = timed_ms(lambda: eng.final_exponentiation(ml))
@@ -389,13 +399,26 @@ def main():
             try:
                 prof = eng.profile_pairing(g1, g2, out_gt)
                 per_kernel = {"pairs": n, "classes": {}, "sum_ms": sum(v[0] for v in prof.values()),
-                              "what": "one pass with every launch bracketed by HIP events on ONE pipeline (the timed pass overlaps two; its wall time is "
-                                      "kernel_ms): ms and launches per kernel class, executed multiply-adds per pairing of that class "
-                                      "(tools/executed_macs.py) and the share of the peak multiply-add issue (256 CU x 4 SIMD x 16 lanes x 2.4 GHz) it reaches"}
+                              "what": "THE per-kernel table (round 6: the only one - the cool-burst timings of single launches that flattered the "
+                                      "Miller program by 10 % are gone): one pass with every launch bracketed by HIP events on ONE pipeline (the timed "
+                                      "pass overlaps two; its wall time is kernel_ms): ms and launches per kernel class, executed multiply-adds per "
+                                      "pairing of that class (tools/executed_macs.py) with the share of the peak multiply-add issue (256 CU x 4 SIMD x "
+                                      "16 lanes x 2.4 GHz) it reaches, and the ALGORITHMIC fraction (SURVEY 8(d)'s reference-shaped count of the work "
+                                      "that class does, x 300 multiply-adds) where the count splits by kernel: the line steps, the Fp12 accumulator of "
+                                      "the Miller loop, and the final exponentiation's classes together"}
+                # SURVEY 8(d) splits by PHASE, not by kernel: the G2 steps + lines (k_prep_lines), the Fp12 accumulator (Miller program), and
+                # the final exponentiation as a whole (every other class together)
+                alg = {"k_prep_lines": FPMUL_LINES, "k_coop<30,4> miller": FPMUL_MILLER - FPMUL_LINES}
+                fexp_ms = sum(v[0] for k_, v in prof.items() if k_ not in alg)
                 for name, (ms_c, cnt) in prof.items():
                     mc = executed["per_kernel"].get(cls_macs[name])
                     per_kernel["classes"][name] = {"ms": ms_c, "launches": cnt, "executed_macs_per_pairing": mc,
-                                                   "executed_frac_of_peak": (n * mc / (ms_c * 1e-3) / PEAK_MACS) if (mc and ms_c > 0) else None}
+                                                   "executed_frac_of_peak": (n * mc / (ms_c * 1e-3) / PEAK_MACS) if (mc and ms_c > 0) else None,
+                                                   "algorithmic_fp_mul_equivalents": alg.get(name),
+                                                   "algorithmic_frac": (n * alg[name] * MACS_PER_FPMUL / (ms_c * 1e-3) / PEAK_MACS) if (name in alg and ms_c > 0) else None}
+                per_kernel["final_exponentiation_classes_together"] = {
+                    "ms": fexp_ms, "algorithmic_fp_mul_equivalents": FPMUL_FEXP,
+                    "algorithmic_frac": (n * FPMUL_FEXP * MACS_PER_FPMUL / (fexp_ms * 1e-3) / PEAK_MACS) if fexp_ms > 0 else None}
             except z.ZkpError as ex:
                 per_kernel = {"error": repr(ex)}
         value = global_pairs * args.steps / dt
@@ -407,7 +430,7 @@ def main():
             sec_all = {}
         phase_exec = lambda key, ms: ((n * sec_all[key]) / (ms * 1e-3) / PEAK_MACS) if (ms and sec_all.get(key)) else None
         traffic = traffic_src = None
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             tpath = os.path.join(ROOT, "profiles", rnd, "pmc", "traffic.json")
             if os.path.exists(tpath) and args.kernel in ("auto", "coop"):
                 with open(tpath) as tf:   # rocprofv3 PMC passes over one 2^20-pair pass, gfx950-corrected (tools/pmc_traffic.py); linear in n
@@ -484,6 +507,32 @@ def main():
                 "what": "BASELINE config 5 as ONE call (zkp_points_check_batch_dev): 2^20 uncompressed (G1, G2) byte strings -> Fp::from_bytes range "
                         "check, G1 / G2 is_valid, fused pairing + Gt::identity() check, status bytes + flags out; decoded points and intermediate "
                         "status bytes stay in HBM.  PCIe-inclusive figure from page-locked host bytes beside it (never `value`)"}
+            # round 6: the two ratios the GPU gate used to assert on wall time are measured HERE
+            nh = min(n, 1 << 18)
+            bh = b1[:nh].clone()
+            bh[::2, 95] ^= 1                                     # y of every second G1 point: off the curve
+            pv_ms = wall_ms(lambda: eng.points_check(b1[:nh], b2[:nh], 1, st1[:nh], st2[:nh], ok[:nh], flag))
+            ph_ms = wall_ms(lambda: eng.points_check(bh, b2[:nh], 1, st1[:nh], st2[:nh], ok[:nh], flag))
+            n_bad = int((st1[:nh] != 0).sum().item())
+            secondary["config5_points_check"]["half_invalid_ratio"] = {
+                "pairs": nh, "all_valid_ms": pv_ms, "every_second_check_invalid_ms": ph_ms, "ratio": ph_ms / pv_ms, "invalid_checks": n_bad,
+                "what": "a check with an invalid point costs its validity tests and nothing else: the valid checks are listed on the device and "
+                        "the pairing kernels size themselves from the device-resident count (no host read-back since round 6)"}
+            del bh
+            k9 = 9
+            n9 = min(n, 1 << 18) // k9 * k9
+            t_new = wall_ms(lambda: eng.multi_miller_loop(g1[:n9], g2[:n9], k9))
+            os.environ["ZKP_COOP_NO_STREAM"] = "1"              # read at zkp_init: a second context runs the rounds-1-4 flow (groups of eight + f12mul)
+            try:
+                eng_old = z.PairingEngine(local_rank)
+                t_old = wall_ms(lambda: eng_old.multi_miller_loop(g1[:n9], g2[:n9], k9))
+                eng_old.close()
+            finally:
+                del os.environ["ZKP_COOP_NO_STREAM"]
+            secondary["k9_shared_squarings_ratio"] = {
+                "pairs": n9, "pairs_per_check": k9, "one_accumulator_ms": t_new, "groups_of_eight_ms": t_old, "ratio": t_new / t_old,
+                "what": "multi_miller_loop() of nine-pair checks: ONE accumulator through the run-time-k Miller program (round 5) against two groups "
+                        "joined by f12mul (rounds 1-4, ZKP_COOP_NO_STREAM=1, a second context in this process)"}
             del b1, b2, st1, st2, hb1, hb2
             # host-pointer C ABI (what a Rust / C host binds): H2D + kernels + D2H inside the call, PCIe-inclusive, never `value`
             hp1, hp2 = eng.host_array((n, 12)), eng.host_array((n, 24))
@@ -501,16 +550,25 @@ def main():
             pin_gt = host_ms(lambda: eng.pairing(hp1, hp2, out=hgt))
             pin_ok = bool(np.array_equal(hgt[:: max(1, n // 4096)], out_gt[:: max(1, n // 4096)].cpu().numpy().view(np.uint64)))
             pin_fl = host_ms(lambda: eng.pairing_check(hp1, hp2, 1))
-            pg1, pg2 = np.array(hp1), np.array(hp2)              # pageable copies
-            pag_gt = host_ms(lambda: eng.pairing(pg1, pg2), reps=1)
+            pg1, pg2 = np.array(hp1), np.array(hp2)              # pageable copies (plain numpy = what a Rust Vec is)
+            pgt = np.zeros((n, 72), dtype=np.uint64)             # the caller's own output array, touched before (a reused Vec)
+            pag_gt = host_ms(lambda: eng.pairing(pg1, pg2, out=pgt), reps=2)
+            pag_ok = bool(np.array_equal(pgt[:: max(1, n // 4096)], out_gt[:: max(1, n // 4096)].cpu().numpy().view(np.uint64)))
+            pag_fresh = host_ms(lambda: eng.pairing(pg1, pg2), reps=1)      # a NEW output array per call: its 600 MB of pages are faulted in inside the call
+            pag_fl = host_ms(lambda: eng.pairing_check(pg1, pg2, 1), reps=2)
             host_api = {"pairs": n,
                         "pinned_gt_out": {"ms": pin_gt, "pairings_per_s": n / pin_gt * 1e3},
                         "pinned_flags_only": {"ms": pin_fl, "pairings_per_s": n / pin_fl * 1e3},
-                        "pageable_gt_out": {"ms": pag_gt, "pairings_per_s": n / pag_gt * 1e3},
-                        "gt_equal_resident_path": pin_ok,
+                        "pageable_gt_out": {"ms": pag_gt, "pairings_per_s": n / pag_gt * 1e3, "over_pinned": pag_gt / pin_gt},
+                        "pageable_gt_out_fresh_pages": {"ms": pag_fresh, "pairings_per_s": n / pag_fresh * 1e3, "over_pinned": pag_fresh / pin_gt},
+                        "pageable_flags_only": {"ms": pag_fl, "pairings_per_s": n / pag_fl * 1e3, "over_pinned": pag_fl / pin_fl},
+                        "gt_equal_resident_path": pin_ok and pag_ok,
                         "what": "zkp_pairing_batch / zkp_pairing_check_batch on HOST arrays: upload, kernels and download inside the call "
-                                "(slices of 2^19 pairs, copies on their own streams); pinned = zkp_host_alloc memory, pageable = plain numpy"}
-            del hp1, hp2, hgt, pg1, pg2
+                                "(slices of 2^19 pairs, copies on their own streams); pinned = zkp_host_alloc memory, pageable = plain numpy: round 6 - "
+                                "the library stages pageable arrays through its own page-locked pieces with worker threads (2 upload, 4 download "
+                                "lanes); pageable_gt_out writes into an output array the caller has used before, ..._fresh_pages into a new "
+                                "np.empty per call (the kernel faults 600 MB of pages in inside the call)"}
+            del hp1, hp2, hgt, pg1, pg2, pgt
         # bit-exact parity of a seeded sample vs the CPU oracle + timing of the oracle on the host cores
         cpu = None
         parity = None
@@ -576,6 +634,45 @@ def main():
                                                 "max_speedup": parts * (m / ms_m) / (n / kern_ms)})
             scaling_bound["what"] = ("measured in this run: one pass over the first 2^20/N pairs of the batch on this GPU against the full pass; "
                                      "max_speedup is the ceiling of the N-GPU strong-scaling curve before collective and host cost anything")
+        # ---- round 6: the small / medium-batch regime - latency and rate of ONE call at n = 1 .. 2^18 checks, k = 1 and 3,
+        # resident inputs, outside the timed region; BASELINE config 2 (2^16 pairs on one GPU) is the n = 65536, k = 1 row
+        sweep = None
+        if world == 1 and not args.bare and not args.no_sweep and args.kernel in ("auto", "coop") and n >= 64:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import batch_sweep
+            sizes = [x for x in batch_sweep.DEFAULT_SIZES if x <= n // 4 or x == 1]
+            rows = batch_sweep.sweep(eng, g1, g2, sizes, (1, 3))
+            full = {1: n / kern_ms}                              # checks per ms of the full pass (k = 1); k = 3: config 4's rate
+            if secondary and secondary.get("config4_three_pair_checks"):
+                full[3] = secondary["config4_three_pair_checks"]["checks"] / secondary["config4_three_pair_checks"]["ms"]
+            for r in rows:
+                r["frac_of_full_rate"] = (r["n"] / r["ms_queued"]) / full[r["k"]] if full.get(r["k"]) else None
+                r.pop("fp", None)
+                if r["n"] == (1 << 16) and r["k"] == 1:
+                    r["baseline_config"] = "config 2: batch of 2^16 random (G1,G2) pairings on one GPU"
+            sweep = {"rows": rows, "full_rate_checks_per_s": {str(k_): v * 1e3 for k_, v in full.items()},
+                     "what": "one zkp_pairing_gt_check_batch_dev call per row (Gt + ok bytes + flag out): ms_call_sync = call + stream synchronisation as a "
+                             "host sees it (mean), ms_queued = calls queued back to back (HIP events), checks_per_s from the latter; "
+                             "frac_of_full_rate against the 2^20-pair pass (k = 1) / config 4 (k = 3) of this run.  A single pairing walks ~30 "
+                             "dependent launches of one wavefront each: launch gaps are 0.7 % of it (profiles/r06/v58_trace_n1.txt), the rest "
+                             "is one wavefront's instruction chain - flat up to ~4096 checks, where the GPU starts to fill"}
+            if cpu and cpu.get("single_thread"):
+                cpu1_ms = 1e3 / cpu["single_thread"]["value"]
+                cpuN_ms = 1e3 / cpu["value"]
+                lat = sorted((r["n"], r["ms_call_sync"]) for r in rows if r["k"] == 1)
+
+                def crossover(per_pairing_ms):
+                    for m in range(1, lat[-1][0] + 1):
+                        gpu_ms = next(ms for nn, ms in lat if nn >= m)        # the latency of the next sweep size up: an upper bound
+                        if gpu_ms < m * per_pairing_ms:
+                            return m
+                    return None
+                sweep["cpu_crossover"] = {
+                    "cpu_single_thread_ms_per_pairing": cpu1_ms, "gpu_ms_one_pairing": lat[0][1],
+                    "n_from_which_one_gpu_call_beats_one_cpu_core": crossover(cpu1_ms),
+                    "n_from_which_one_gpu_call_beats_all_cpu_threads": crossover(cpuN_ms), "cpu_threads": cpu["cores"],
+                    "what": "CPU restatement (oracle/, -O3) on this box's host cores against ONE call on resident inputs; below the crossover a caller "
+                            "with a single pairing is better served by a CPU core (1 pairing: %.2f ms on the GPU, %.2f ms on one core)" % (lat[0][1], cpu1_ms)}
         roof = {"bound": "valu-int (neither hbm nor mfma: 384-bit modular arithmetic; algorithmic intensity 6.56 M MAC per 864 B of I/O = 7,600 MAC/B, "
                          "executed intensity ~30 MAC/B with the line stream and the per-check state that pass through HBM - still 6x above the "
                          "4.9 MAC/B ridge of 39.3 T MAC/s over 8 TB/s)",
@@ -585,6 +682,8 @@ def main():
                               "work the kernels avoid (lazy reduction, Karatsuba, compressed squarings); executed_frac_of_peak beside it is what the "
                               "multiply-add pipe actually issues",
                 "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_over_algorithmic_io": (traffic / (864.0 * n)) if traffic else None,      # 864 B = 288 in + 576 out per pairing
+
                 "peak_clock_ghz": NOMINAL_GHZ, "sustained_clock_ghz": sustained_ghz,
                 "frac_at_sustained_clock": (achieved / (LANES_PER_CLK * sustained_ghz * 1e9)) if sustained_ghz else None,
                 "kernel_ms": kern_ms, "algorithmic_macs_per_pairing": MACS_PER_PAIRING,
@@ -599,14 +698,6 @@ def main():
                                              "executed_frac_of_peak": phase_exec("final_exponentiation", fe_ms),
                                              "kernels": "k_coop<24,34> (fexp_a, fexp_c0..5), k_batch_inv, k_ksq, k_kdec_a, k_kdec_b"}},
                 "kernels_executed": per_kernel,
-                "kernels": {
-                    "k_prep_lines": {"ms": prep_ms, "frac": phase(FPMUL_LINES, prep_ms), "fp_mul_equivalents": FPMUL_LINES,
-                                     "what": "G2 doubling / addition steps + line coefficients as the fused path runs them (k_prep_lines<true>: homogeneous projective, "
-                                             "freely scaled lines); one 2^16-pair launch timed alone, scaled to the shard"},
-                    "k_coop miller": {"ms": mil_ms, "frac": phase(FPMUL_MILLER - FPMUL_LINES, mil_ms), "fp_mul_equivalents": FPMUL_MILLER - FPMUL_LINES,
-                                      "what": "Fp12 accumulator: 68 line products + 63 squarings; one 2^16-check launch timed alone, scaled"},
-                    "final exponentiation kernels": {"ms": fe_ms, "frac": phase(FPMUL_FEXP, fe_ms), "fp_mul_equivalents": FPMUL_FEXP,
-                                                     "what": "fexp_a, k_batch_inv, the phase C plan (see profiles/r04/*_kernel_stats.txt for its split)"}},
                 "launch": "one pass over the resident batch = phase A per 2^16-check chunk on two overlapped HIP streams (k_prep_lines, k_coop "
                           "miller, k_coop fexp_a), ONE k_batch_inv, then the phase C plan over the whole shard: six step programs "
                           "alternating with five compressed squaring runs (k_ksq: 57 squarings, 3 snapshots each) and their decompression (k_kdec_a, k_batch_inv, "
@@ -635,6 +726,7 @@ def main():
                         "all-reduce(MIN) of the flag (mean of 8, after a barrier); step_wall_ms: the rank's own wall time per timed step",
                 "single_gpu_bound": "see strong_scaling_bound of the N = 1 line of the same build (a shard of 2^20 / N pairs timed on one GPU)"},
             "strong_scaling_bound": scaling_bound,
+            "batch_sweep": sweep,
         }
         print(json.dumps(line), flush=True)
     if abi_hung:

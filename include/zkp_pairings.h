@@ -275,7 +275,11 @@ int zkp_pairing_batch_multi(zkp_ctx* const* ctxs, int n_ctx, const uint64_t* g1,
  * Failure on one rank: a rank whose OWN block fails (bad arguments, non-canonical limbs under zkp_set_validate, a HIP error) still
  * takes part in the collective - with flag 0 (AND-reduce) or the zero record (all-gather variant) - so no peer is left waiting and
  * every rank reads all_ok / is_one = 0; the failing rank returns its own status afterwards.  Only a call without context,
- * output flag or communicator returns before the collective (ZKP_ERR_ARG / ZKP_ERR_COMM).  No reference
+ * output flag or communicator returns before the collective (ZKP_ERR_ARG / ZKP_ERR_COMM).
+ * zkp_comm_init_rank itself is a collective: every rank must call it (a rank that cannot - no context, no device - makes the others
+ * wait, as with any bootstrap).  Its local failures come AFTER the bootstrap (round 6): a rank without memory for the communicator's
+ * records aborts its side and returns ZKP_ERR_OOM; the peers cannot see that, so agree on the ranks' statuses over the host's own
+ * channel before the first collective (bench.py does: one gloo all-reduce(MIN) of "init ok").  No reference
  * counterpart (the reference is a single-threaded host crate); the torch.distributed flavour of the same step is
  * zkvm_pairings_amd/dist.py. */
 #define ZKP_COMM_ID_BYTES 128

@@ -5,7 +5,7 @@
 # the bench line).  Raw profiler output goes to gpurun_out/prof_<tag>/ (scratch); the summaries are written to
 # gpurun_out/profiles_<tag>/ and copied to profiles/<round>/ by hand after a look.
 set -e -o pipefail
-round=${1:-r05}; tag=${2:-v51}
+round=${1:-r06}; tag=${2:-v60}
 root=$PWD
 raw=$root/gpurun_out/prof_$tag; out=$root/gpurun_out/profiles_$tag
 rm -rf "$raw" "$out"; mkdir -p "$raw" "$out/pmc"

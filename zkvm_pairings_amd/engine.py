@@ -370,15 +370,19 @@ class PairingEngine:
         null = ctypes.c_void_p(None)
         out = ctypes.c_int(0)
         if entry == "check":
-            self._lib.zkp_pairing_check_batch_allreduce(self._h, null, null, null, null, 1, 1, null, ctypes.byref(out))
+            rc = self._lib.zkp_pairing_check_batch_allreduce(self._h, null, null, null, null, 1, 1, null, ctypes.byref(out))
         elif entry == "check_dev":
-            self._lib.zkp_pairing_check_batch_allreduce_dev(self._h, null, null, null, null, 1, 1, null, self._tp(dev_flag), self._stream())
+            rc = self._lib.zkp_pairing_check_batch_allreduce_dev(self._h, null, null, null, null, 1, 1, null, self._tp(dev_flag), self._stream())
         elif entry == "gt_check_dev":
-            self._lib.zkp_pairing_gt_check_batch_allreduce_dev(self._h, null, null, null, null, 1, 1, null, null, self._tp(dev_flag), self._stream())
+            rc = self._lib.zkp_pairing_gt_check_batch_allreduce_dev(self._h, null, null, null, null, 1, 1, null, null, self._tp(dev_flag), self._stream())
         elif entry == "points":
-            self._lib.zkp_points_check_batch_allreduce(self._h, null, null, 1, 1, null, null, null, ctypes.byref(out))
+            rc = self._lib.zkp_points_check_batch_allreduce(self._h, null, null, 1, 1, null, null, null, ctypes.byref(out))
         else:
-            self._lib.zkp_pairing_product_check_allgather(self._h, null, null, null, null, 1, null, ctypes.byref(out))
+            rc = self._lib.zkp_pairing_product_check_allgather(self._h, null, null, null, null, 1, null, ctypes.byref(out))
+        # the library refuses the arguments (ZKP_ERR_ARG = -1) AFTER it has taken part in the collective; ZKP_ERR_COMM (-6) means there
+        # was no communicator / RCCL failed, i.e. nothing was joined - the caller's error should say so
+        self.last_join_status = rc
+        return rc
 
     def and_allreduce(self, flag):
         """in-place AND (all-reduce MIN) of an int32[1] tensor of {0,1} over the communicator's ranks, on the current stream"""
@@ -419,7 +423,13 @@ class PairingEngine:
         """device tensors only: pairing_gt_check of this rank's block + the AND over all ranks in all_ok (int32[1], required) -
         zkp_pairing_gt_check_batch_allreduce_dev, BASELINE config 3 as one call per rank"""
         import torch
-        self._t_check(all_ok, None, "all_ok", rows=1, dtypes=(torch.int32,))
+        try:
+            self._t_check(all_ok, None, "all_ok", rows=1, dtypes=(torch.int32,))
+        except (TypeError, ValueError, AttributeError):
+            # a flag tensor this rank cannot even hand to the library (wrong dtype / shape / device, not a tensor): the peers are waiting
+            # in the collective all the same - join it with a flag of the wrapper's own, then raise
+            self._join_failed("gt_check_dev", torch.empty(1, dtype=torch.int32, device=torch.device("cuda", self.device)))
+            raise
         try:
             n = self._t_pairs(g1, g2, inf1, inf2, k)
             if out_gt is not None:
