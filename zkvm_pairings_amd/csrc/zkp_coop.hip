@@ -1798,7 +1798,7 @@ __device__ __constant__ const int32_t PL[N] = {ZKP30_P_LIMBS};
 
 __device__ __forceinline__ void divsteps30(int32_t& eta, uint32_t f, uint32_t g, int32_t& u_, int32_t& v_, int32_t& q_, int32_t& r_) {
     uint32_t u = 1, v = 0, q = 0, r = 1, e = (uint32_t)eta;
-#pragma unroll 1
+#pragma unroll 6      // round 6: five trips instead of thirty - a taken branch costs a lone wavefront about three of the step's 24 instructions
     for (int i = 0; i < 30; i++) {
         uint32_t c1 = (uint32_t)((int32_t)e >> 31);          // eta < 0  <=>  delta > 0
         const uint32_t c2 = 0u - (g & 1u);
@@ -1811,8 +1811,15 @@ __device__ __forceinline__ void divsteps30(int32_t& eta, uint32_t f, uint32_t g,
     }
     eta = (int32_t)e; u_ = (int32_t)u; v_ = (int32_t)v; q_ = (int32_t)q; r_ = (int32_t)r;
 }
+// Round 6: the limbs and matrix entries are pinned to 32-bit registers (an empty asm the optimiser cannot see through).  Without it
+// LLVM carries a limb as the masked 64-bit carry word it came from and expands every (int64) u * limb into the 64 x 64-bit pattern
+// (v_mad_u64_u32 x 2 + v_mul_lo_u32 x 2 + moves: 562 instructions for the two updates of a batch); with 32-bit operands each product
+// is ONE v_mad_i64_i32.  k_batch_inv is one lane's dependent chain - the six launches of a pass are what a small or medium batch pays in
+// full (profiles/r06: 0.11-0.18 ms each, whatever the batch) - so instructions are time here.
+#define ZKP_SG_PIN32(x) asm volatile("" : "+v"(x))
 // (f, g) <- (u f + v g, q f + r g) / 2^30, exactly
 __device__ __forceinline__ void update_fg(int32_t* f, int32_t* g, int32_t u, int32_t v, int32_t q, int32_t r) {
+    ZKP_SG_PIN32(u); ZKP_SG_PIN32(v); ZKP_SG_PIN32(q); ZKP_SG_PIN32(r);
     int64_t cf = (int64_t)u * f[0] + (int64_t)v * g[0];
     int64_t cg = (int64_t)q * f[0] + (int64_t)r * g[0];
     cf >>= 30; cg >>= 30;                                      // the low 30 bits are zero by construction
@@ -1822,17 +1829,21 @@ __device__ __forceinline__ void update_fg(int32_t* f, int32_t* g, int32_t u, int
         cg += (int64_t)q * f[i] + (int64_t)r * g[i];
         f[i - 1] = (int32_t)cf & M30; cf >>= 30;
         g[i - 1] = (int32_t)cg & M30; cg >>= 30;
+        ZKP_SG_PIN32(f[i - 1]); ZKP_SG_PIN32(g[i - 1]);
     }
     f[N - 1] = (int32_t)cf; g[N - 1] = (int32_t)cg;
+    ZKP_SG_PIN32(f[N - 1]); ZKP_SG_PIN32(g[N - 1]);
 }
 // (d, e) <- (u d + v e, q d + r e) / 2^30 mod p; inputs and outputs in (-2p, p)
 __device__ __forceinline__ void update_de(int32_t* d, int32_t* e, int32_t u, int32_t v, int32_t q, int32_t r) {
+    ZKP_SG_PIN32(u); ZKP_SG_PIN32(v); ZKP_SG_PIN32(q); ZKP_SG_PIN32(r);
     const int32_t sd = d[N - 1] >> 31, se = e[N - 1] >> 31;
     int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);   // add p to a negative d / e first
     int64_t cd = (int64_t)u * d[0] + (int64_t)v * e[0];
     int64_t ce = (int64_t)q * d[0] + (int64_t)r * e[0];
     md -= (int32_t)((ZKP30_PINV * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);   // multiple of p that clears the low 30 bits
     me -= (int32_t)((ZKP30_PINV * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+    ZKP_SG_PIN32(md); ZKP_SG_PIN32(me);
     cd += (int64_t)PL[0] * md; ce += (int64_t)PL[0] * me;
     cd >>= 30; ce >>= 30;
 #pragma unroll
@@ -1841,8 +1852,10 @@ __device__ __forceinline__ void update_de(int32_t* d, int32_t* e, int32_t u, int
         ce += (int64_t)q * d[i] + (int64_t)r * e[i] + (int64_t)PL[i] * me;
         d[i - 1] = (int32_t)cd & M30; cd >>= 30;
         e[i - 1] = (int32_t)ce & M30; ce >>= 30;
+        ZKP_SG_PIN32(d[i - 1]); ZKP_SG_PIN32(e[i - 1]);
     }
     d[N - 1] = (int32_t)cd; e[N - 1] = (int32_t)ce;
+    ZKP_SG_PIN32(d[N - 1]); ZKP_SG_PIN32(e[N - 1]);
 }
 // x in (-2p, p), negated when sign < 0, brought to [0, p)
 __device__ __forceinline__ void normalize(int32_t* x, int32_t sign) {
