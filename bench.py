@@ -564,10 +564,12 @@ def main():
                         "pageable_flags_only": {"ms": pag_fl, "pairings_per_s": n / pag_fl * 1e3, "over_pinned": pag_fl / pin_fl},
                         "gt_equal_resident_path": pin_ok and pag_ok,
                         "what": "zkp_pairing_batch / zkp_pairing_check_batch on HOST arrays: upload, kernels and download inside the call "
-                                "(slices of 2^19 pairs, copies on their own streams); pinned = zkp_host_alloc memory, pageable = plain numpy: round 6 - "
-                                "the library stages pageable arrays through its own page-locked pieces with worker threads (2 upload, 4 download "
-                                "lanes); pageable_gt_out writes into an output array the caller has used before, ..._fresh_pages into a new "
-                                "np.empty per call (the kernel faults 600 MB of pages in inside the call)"}
+                                "(slices of 2^19 pairs, copies on their own streams); pinned = zkp_host_alloc memory, pageable = plain numpy.  "
+                                "pageable_gt_out writes into an output array the caller has used before: ROCm's own pageable copies are then at the "
+                                "page-locked time (a staging layer built in round 6 lost 2.7 % against them and was removed: "
+                                "profiles/r06/host_api_staging_ab.txt); ..._fresh_pages writes into a new np.empty per call - ~25 ms of page faults "
+                                "inside the call (the driver faults 600 MB in when it pins them) + ~25 ms of mmap / munmap in the caller's allocator: "
+                                "what round 5's 312 ms was.  Reuse the output buffer"}
             del hp1, hp2, hgt, pg1, pg2, pgt
         # bit-exact parity of a seeded sample vs the CPU oracle + timing of the oracle on the host cores
         cpu = None
@@ -656,6 +658,25 @@ def main():
                              "frac_of_full_rate against the 2^20-pair pass (k = 1) / config 4 (k = 3) of this run.  A single pairing walks ~30 "
                              "dependent launches of one wavefront each: launch gaps are 0.7 % of it (profiles/r06/v58_trace_n1.txt), the rest "
                              "is one wavefront's instruction chain - flat up to ~4096 checks, where the GPU starts to fill"}
+            # a STREAM of medium batches (what a verifier with many config-2-sized jobs has): the same calls alternating over two / three
+            # contexts on as many streams - one call's latency-bound islands run beside another call's Miller loop
+            try:
+                import two_contexts
+                streams = []
+                for ns_ in (1 << 14, 1 << 16, 1 << 17):
+                    if ns_ * 3 > n:
+                        continue
+                    tc_ = two_contexts.run(ns_, 12, 3)
+                    streams.append({"pairs_per_call": ns_, "calls": tc_["calls"], "gt_equal": tc_["gt_equal"],
+                                    "pairings_per_s": {str(m): tc_["contexts_%d" % m]["pairings_per_s"] for m in (1, 2, 3)},
+                                    "frac_of_full_rate": {str(m): tc_["contexts_%d" % m]["pairings_per_s"] / (full[1] * 1e3) for m in (1, 2, 3)}})
+                sweep["streams_of_medium_batches"] = {
+                    "rows": streams,
+                    "what": "12 calls of n pairs queued back to back: on ONE context (key 1), alternating over TWO / THREE contexts, each with its own "
+                            "stream, workspace and pipelines (keys 2, 3; tools/two_contexts.py).  A single medium call cannot hide its six "
+                            "inversion launches; several calls in flight hide each other's - the way to run a stream of config-2-sized batches"}
+            except Exception as ex:      # a diagnostic outside the timed region: never costs the line
+                sweep["streams_of_medium_batches"] = {"error": repr(ex)}
             if cpu and cpu.get("single_thread"):
                 cpu1_ms = 1e3 / cpu["single_thread"]["value"]
                 cpuN_ms = 1e3 / cpu["value"]

@@ -675,19 +675,15 @@ def test_page_locked_host_arrays(monkeypatch):
         e.close()
 
 
-def test_pageable_host_arrays_are_staged_by_worker_threads(monkeypatch):
-    """round 6: pageable host arrays (plain numpy = what a Rust Vec is) go through library-owned page-locked pieces filled / drained by
-    worker threads (two upload lanes, four download lanes, two pieces each).  Small pieces and small slices so that every lane cycles
-    through its pieces many times: the sliced pipeline (pairing, Gt out; flags only), the one-shot entry points and the points check
-    give the bytes of the runtime's own pageable copies (ZKP_HOST_STAGE=0) and of page-locked arrays - ragged sizes, an unaligned
-    output view, a piece larger than an array, and an output nobody touched before (fresh pages)."""
+def test_pageable_host_arrays_fresh_and_reused_outputs(monkeypatch):
+    """pageable host arrays (plain numpy = what a Rust Vec is) through the sliced pipeline and the one-shot entry points: an output array
+    nobody touched before (fresh pages, an offset view of them), a reused one and a page-locked one receive the same bytes.  (Round 6
+    measured that ROCm's own pageable copies are at the page-locked time once the output buffer is reused - a staging layer built here
+    lost 2.7 % and was removed, profiles/r06/host_api_staging_ab.txt; what a NEW output per call costs is page faults.)"""
     from zkvm_pairings_amd import PairingEngine, synthetic
     n = 6007
     res = {}
-    for tag, stage, piece, slc in (("plain", "0", "4096", "1000"), ("staged", "1", "4096", "1000"), ("staged_big_pieces", "1", "1048576", "1000"),
-                                   ("staged_one_shot", "1", "8192", "100000")):
-        monkeypatch.setenv("ZKP_HOST_STAGE", stage)
-        monkeypatch.setenv("ZKP_HOST_STAGE_BYTES", piece)
+    for tag, slc in (("sliced", "1000"), ("one_shot", "100000")):
         monkeypatch.setenv("ZKP_HOST_SLICE", slc)
         e = PairingEngine(0)
         try:
@@ -695,25 +691,23 @@ def test_pageable_host_arrays_are_staged_by_worker_threads(monkeypatch):
                 g1, g2, _, _ = synthetic.random_pairs(e, n, seed=606)
                 inf1 = np.zeros(n, dtype=np.uint8)
                 inf1[[0, 999, 1000, 6006]] = 1
-                neg = g1.copy()
-                neg[:, 6:] = e.fp_op("neg", np.ascontiguousarray(g1[:, 6:]))
-                G1 = np.stack([g1, neg], axis=1).reshape(2 * n, 12)
-                G2 = np.repeat(g2, 2, axis=0)
             back = np.empty(n * 72 + 3, dtype=np.uint64)                    # never touched: fresh pages, and an offset view of them
-            gt = e.pairing(g1, g2, inf1, None, out=back[3:].reshape(n, 72))
-            ok, allok = e.pairing_check(G1, G2, 2)                          # every check the identity; 12014 pairs: sliced above 8 x 1000
+            fresh = e.pairing(g1, g2, inf1, None, out=back[3:].reshape(n, 72)).copy()
+            reused = np.zeros((n, 72), dtype=np.uint64)
+            e.pairing(g1, g2, inf1, None, out=reused)
+            e.pairing(g1, g2, inf1, None, out=reused)
+            p1, p2, pg = e.host_array((n, 12)), e.host_array((n, 24)), e.host_array((n, 72))
+            p1[:], p2[:] = g1, g2
+            e.pairing(p1, p2, inf1, None, out=pg)
+            assert np.array_equal(fresh, reused) and np.array_equal(fresh, pg), tag
             ok1, allok1 = e.pairing_check(g1, g2, 1, inf1, None)
-            b1 = e.encode_points(g1, 1)
-            st = e.points_check(np.frombuffer(b1, dtype=np.uint8).reshape(n, 96), np.frombuffer(e.encode_points(g2, 2), dtype=np.uint8).reshape(n, 192), 1)
-            res[tag] = (gt.copy(), ok, allok, ok1, allok1, st[0], st[1], st[2], st[3])
+            assert np.array_equal(ok1, inf1) and not allok1
+            res[tag] = fresh
+            del p1, p2, pg
         finally:
             e.close()
-    want = res["plain"]
-    assert want[1].all() and want[2] and np.array_equal(want[3], inf1) and not want[4] and not want[5].any() and not want[8]
-    assert np.array_equal(want[0][:64], o.pairing_batch(g1[:64], g2[:64], inf1[:64], None, NTHREADS))
-    for tag, got in res.items():
-        for a, b in zip(want, got):
-            assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b, tag
+    assert np.array_equal(res["sliced"], res["one_shot"])
+    assert np.array_equal(res["sliced"][:64], o.pairing_batch(g1[:64], g2[:64], inf1[:64], None, NTHREADS))
 
 
 def test_divstep_inversion_equals_fermat(monkeypatch):

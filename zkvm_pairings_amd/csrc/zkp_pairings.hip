@@ -13,8 +13,6 @@
 #include <unistd.h>
 #include <new>
 #include <string>
-#include <thread>
-#include <vector>
 
 #include "../../include/zkp_pairings.h"
 #include "zkp_field.hpp"
@@ -458,20 +456,6 @@ struct zkp_ctx {
     } hs[2];
     hipStream_t s_in = nullptr, s_out = nullptr;
     size_t host_slice = (size_t)1 << 19;
-    // round 6: PAGEABLE host arrays (a plain Vec / numpy array) go through library-owned page-locked staging pieces filled / drained by
-    // worker threads, each with its own stream and two pieces, so that the memcpy of one piece runs beside the DMA of the previous one
-    // and beside the kernels (a pageable hipMemcpyAsync stages serially inside the runtime and blocks the calling thread).
-    // Lanes 0 .. STAGE_UP-1 carry uploads, the rest downloads; created on first use, kept for the context's life.
-    static constexpr int STAGE_UP = 2, STAGE_DOWN = 4, STAGE_LANES = STAGE_UP + STAGE_DOWN;
-    struct StageLane {
-        hipStream_t s = nullptr;
-        void* pin[2] = {nullptr, nullptr};
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        hipEvent_t fin = nullptr;
-    } lane[STAGE_LANES];
-    bool lanes_ready = false;
-    size_t stage_bytes = (size_t)4 << 20;     // ZKP_HOST_STAGE_BYTES: bytes per staging piece
-    int stage_threads = 1;                    // ZKP_HOST_STAGE: 0 = never stage (the runtime's own pageable copies, rounds 1-5)
     hipDeviceProp_t prop;
     zkp::CoopState coop;
     // zkp_points_check_batch: decoded points, infinity flags, decode / is_valid / merged status bytes, ok bytes (grow-only)
@@ -654,153 +638,6 @@ int validate_dev(zkp_ctx* c, const uint64_t* d, size_t n_fp) {
 
 struct Staged { const uint64_t *g1, *g2; const uint8_t *i1, *i2; };
 
-// ---- pageable host arrays through page-locked staging pieces (zkp_ctx::lane)
-// plain malloc / Vec / numpy memory?  (page-locked memory - zkp_host_alloc, zkp_host_register, hipHostMalloc - is known to the runtime)
-bool is_pageable(const void* p) {
-    if (!p) return false;
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return true; }
-    return a.type == hipMemoryTypeUnregistered;
-}
-int ensure_lanes(zkp_ctx* c) {
-    if (c->lanes_ready) return ZKP_OK;
-    for (int i = 0; i < zkp_ctx::STAGE_LANES; i++) {
-        zkp_ctx::StageLane& L = c->lane[i];
-        if (!L.s) HIPCHK(c, hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
-        for (int j = 0; j < 2; j++) {
-            if (!L.pin[j]) { HIPCHK(c, hipHostMalloc(&L.pin[j], c->stage_bytes, hipHostMallocDefault)); zkp_dbg_alloc("stage.pin", L.pin[j], c->stage_bytes); }
-            if (!L.ev[j]) HIPCHK(c, hipEventCreateWithFlags(&L.ev[j], hipEventDisableTiming));
-        }
-        if (!L.fin) HIPCHK(c, hipEventCreateWithFlags(&L.fin, hipEventDisableTiming));
-    }
-    c->lanes_ready = true;
-    return ZKP_OK;
-}
-struct StageSeg { char* dev; char* host; size_t bytes; };
-// One direction's copies of one slice, cut into pieces of stage_bytes; worker t of T takes pieces t, t + T, ...  Upload: memcpy into a
-// page-locked piece, DMA from it (the piece is reused once its DMA has ended); the lane's `fin` event follows its last DMA - the thread
-// ends when everything is ENQUEUED.  Download: DMA into a piece, memcpy out of the previous one meanwhile; the thread ends when its
-// bytes are in the caller's array.  `after` (may be null): what the lanes' streams wait for first (the slot's previous use).
-struct StageJob {
-    zkp_ctx* c = nullptr;
-    bool upload = false;
-    int lane0 = 0, T = 0;
-    std::vector<StageSeg> segs;
-    std::vector<std::thread> th;
-    std::vector<hipError_t> rc;
-    bool active = false;
-
-    static void worker(StageJob* j, int t, hipEvent_t after) {
-        zkp_ctx* c = j->c;
-        zkp_ctx::StageLane& L = c->lane[j->lane0 + t];
-        hipError_t e = hipSetDevice(c->device);
-        if (e == hipSuccess && after) e = hipStreamWaitEvent(L.s, after, 0);
-        const size_t P = c->stage_bytes;
-        size_t piece = 0, mine = 0;
-        char* prev_host = nullptr;          // download: the piece whose DMA is in flight
-        size_t prev_len = 0;
-        int prev_slot = 0;
-        for (size_t si = 0; si < j->segs.size() && e == hipSuccess; si++) {
-            const StageSeg& sg = j->segs[si];
-            for (size_t off = 0; off < sg.bytes && e == hipSuccess; off += P, piece++) {
-                if ((int)(piece % (size_t)j->T) != t) continue;
-                const size_t len = sg.bytes - off < P ? sg.bytes - off : P;
-                const int slot = (int)(mine & 1);
-                if (j->upload) {
-                    e = hipEventSynchronize(L.ev[slot]);      // the DMA that last read this piece - of this job or of the previous one (a
-                                                              // job ends when its copies are ENQUEUED); never recorded: returns at once
-                    if (e != hipSuccess) break;
-                    memcpy(L.pin[slot], sg.host + off, len);
-                    e = hipMemcpyAsync(sg.dev + off, L.pin[slot], len, hipMemcpyHostToDevice, L.s);
-                    if (e == hipSuccess) e = hipEventRecord(L.ev[slot], L.s);
-                } else {
-                    e = hipMemcpyAsync(L.pin[slot], sg.dev + off, len, hipMemcpyDeviceToHost, L.s);
-                    if (e == hipSuccess) e = hipEventRecord(L.ev[slot], L.s);
-                    if (e == hipSuccess && prev_host) {
-                        e = hipEventSynchronize(L.ev[prev_slot]);
-                        if (e == hipSuccess) memcpy(prev_host, L.pin[prev_slot], prev_len);
-                    }
-                    prev_host = sg.host + off; prev_len = len; prev_slot = slot;
-                }
-                mine++;
-            }
-        }
-        if (!j->upload && prev_host) {
-            // the last piece; after an error the DMA that may still write the page-locked piece is waited for all the same
-            const hipError_t e2 = hipEventSynchronize(L.ev[prev_slot]);
-            if (e == hipSuccess && e2 == hipSuccess) memcpy(prev_host, L.pin[prev_slot], prev_len);
-            if (e == hipSuccess) e = e2;
-        }
-        if (j->upload) {
-            const hipError_t e2 = hipEventRecord(L.fin, L.s);
-            if (e == hipSuccess) e = e2;
-            if (e != hipSuccess) (void)hipStreamSynchronize(L.s);      // nothing may still read the page-locked pieces
-        }
-        j->rc[t] = e;
-    }
-    int start(zkp_ctx* ctx, bool up, hipEvent_t after) {
-        c = ctx; upload = up;
-        lane0 = up ? 0 : zkp_ctx::STAGE_UP;
-        T = up ? zkp_ctx::STAGE_UP : zkp_ctx::STAGE_DOWN;
-        rc.assign(T, hipSuccess);
-        th.clear();
-        active = true;
-        try {
-            for (int t = 0; t < T; t++) th.emplace_back(worker, this, t, after);
-        } catch (...) {            // no thread to be had: the ones that started are joined, the call fails
-            (void)finish(nullptr);
-            c->err = "zkp: could not start a staging thread";
-            return ZKP_ERR_HIP;
-        }
-        return ZKP_OK;
-    }
-    // joins the workers; an upload's DMAs are then enqueued and `join_into` (may be null) is made to wait for them
-    int finish(hipStream_t join_into) {
-        if (!active) return ZKP_OK;
-        for (auto& t : th)
-            if (t.joinable()) t.join();
-        th.clear();
-        active = false;
-        segs.clear();
-        for (int t = 0; t < T; t++)
-            if (rc[t] != hipSuccess) { c->err = std::string("staged copy: ") + hipGetErrorString(rc[t]); return rc[t] == hipErrorOutOfMemory ? ZKP_ERR_OOM : ZKP_ERR_HIP; }
-        if (upload && join_into)
-            for (int t = 0; t < T; t++) HIPCHK(c, hipStreamWaitEvent(join_into, c->lane[lane0 + t].fin, 0));
-        return ZKP_OK;
-    }
-    ~StageJob() { (void)finish(nullptr); }      // threads are joined on EVERY way out of the entry point
-};
-// upload of whole arrays on the context's stream, staged when an array is pageable and large (the one-shot entry points)
-int upload_arrays(zkp_ctx* c, std::initializer_list<StageSeg> arrays, hipStream_t s) {
-    StageJob job;
-    for (const StageSeg& a : arrays) {
-        if (!a.bytes) continue;
-        if (c->stage_threads && a.bytes >= c->stage_bytes && is_pageable(a.host)) job.segs.push_back(a);
-        else HIPCHK(c, hipMemcpyAsync(a.dev, a.host, a.bytes, hipMemcpyHostToDevice, s));
-    }
-    if (job.segs.empty()) return ZKP_OK;
-    int rc = ensure_lanes(c);
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->ev0, s));       // the staged pieces overwrite workspace the stream's earlier work may still read
-    if ((rc = job.start(c, true, c->ev0))) return rc;
-    return job.finish(s);
-}
-// ... and the download of one whole array behind everything queued on `s` (the caller synchronises nothing else: the bytes are there on return)
-int download_array(zkp_ctx* c, void* host, const void* dev, size_t bytes, hipStream_t s) {
-    if (!bytes) return ZKP_OK;
-    if (!(c->stage_threads && bytes >= c->stage_bytes && is_pageable(host))) {
-        HIPCHK(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
-        return ZKP_OK;
-    }
-    int rc = ensure_lanes(c);
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->ev1, s));
-    StageJob job;
-    job.segs.push_back({(char*)dev, (char*)host, bytes});
-    if ((rc = job.start(c, false, c->ev1))) return rc;
-    return job.finish(nullptr);
-}
-
 int ensure_slot(zkp_ctx* c, zkp_ctx::HostSlot* h, int which, size_t bytes) {
     if (bytes <= h->cap[which]) return ZKP_OK;
     if (h->buf[which]) { HIPCHK(c, hipFree(h->buf[which])); h->buf[which] = nullptr; h->cap[which] = 0; }
@@ -837,45 +674,30 @@ int host_sliced_impl(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const u
     }
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, c->d_flag + 1, 1);
     HIPCHK(c, hipGetLastError());
-    // pageable arrays (round 6): the big copies of a slice are staged by worker threads (StageJob) - at most one upload job and one
-    // download job are in flight, each joined before the workspace slot it touches is used again; both are joined on every way out
-    const bool st_on = c->stage_threads != 0;
-    const bool pg1 = st_on && is_pageable(g1), pg2 = st_on && is_pageable(g2), pgo = st_on && out_gt && is_pageable(out_gt);
-    if ((pg1 || pg2 || pgo) && (rc = ensure_lanes(c))) return rc;
-    StageJob up_job, down_job;
     auto upload = [&](size_t i) -> int {
         zkp_ctx::HostSlot* h = &c->hs[i & 1];
         const size_t c0 = i * sc, ns = n_checks - c0 < sc ? n_checks - c0 : sc, p0 = c0 * k, np = ns * k;
         if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_in, h->done, 0));   // slice i-2 has finished reading these buffers
-        if (pg1) up_job.segs.push_back({(char*)h->buf[0], (char*)(g1 + 12 * p0), np * 96});
-        else HIPCHK(c, hipMemcpyAsync(h->buf[0], g1 + 12 * p0, np * 96, hipMemcpyHostToDevice, c->s_in));
-        if (pg2) up_job.segs.push_back({(char*)h->buf[1], (char*)(g2 + 24 * p0), np * 192});
-        else HIPCHK(c, hipMemcpyAsync(h->buf[1], g2 + 24 * p0, np * 192, hipMemcpyHostToDevice, c->s_in));
+        HIPCHK(c, hipMemcpyAsync(h->buf[0], g1 + 12 * p0, np * 96, hipMemcpyHostToDevice, c->s_in));
+        HIPCHK(c, hipMemcpyAsync(h->buf[1], g2 + 24 * p0, np * 192, hipMemcpyHostToDevice, c->s_in));
         if (inf1) HIPCHK(c, hipMemcpyAsync(h->buf[2], inf1 + p0, np, hipMemcpyHostToDevice, c->s_in));
         if (inf2) HIPCHK(c, hipMemcpyAsync(h->buf[3], inf2 + p0, np, hipMemcpyHostToDevice, c->s_in));
         HIPCHK(c, hipEventRecord(h->in, c->s_in));
-        if (!up_job.segs.empty() && (rc = up_job.start(c, true, i >= 2 ? h->done : nullptr))) return rc;
         return ZKP_OK;
     };
     auto download = [&](size_t i) -> int {
         zkp_ctx::HostSlot* h = &c->hs[i & 1];
         const size_t c0 = i * sc, ns = n_checks - c0 < sc ? n_checks - c0 : sc;
         HIPCHK(c, hipStreamWaitEvent(c->s_out, h->done, 0));
-        if (out_gt && !pgo) HIPCHK(c, hipMemcpyAsync(out_gt + 72 * c0, h->buf[4], ns * 576, hipMemcpyDeviceToHost, c->s_out));
+        if (out_gt) HIPCHK(c, hipMemcpyAsync(out_gt + 72 * c0, h->buf[4], ns * 576, hipMemcpyDeviceToHost, c->s_out));
         if (ok) HIPCHK(c, hipMemcpyAsync(ok + c0, h->buf[5], ns, hipMemcpyDeviceToHost, c->s_out));
         HIPCHK(c, hipEventRecord(h->out, c->s_out));
-        if (pgo) {
-            down_job.segs.push_back({(char*)h->buf[4], (char*)(out_gt + 72 * c0), ns * 576});
-            if ((rc = down_job.start(c, false, h->done))) return rc;
-        }
         return ZKP_OK;
     };
     if ((rc = upload(0))) return rc;
     for (size_t i = 0; i < nsl; i++) {
         zkp_ctx::HostSlot* h = &c->hs[i & 1];
         const size_t c0 = i * sc, ns = n_checks - c0 < sc ? n_checks - c0 : sc;
-        if ((rc = up_job.finish(c->stream))) return rc;                     // slice i's staged pieces are enqueued: the kernels wait for their DMAs
-        if ((rc = down_job.finish(nullptr))) return rc;                     // slice i-2's Gt has reached the caller's array: its output slot is free again
         HIPCHK(c, hipStreamWaitEvent(c->stream, h->in, 0));
         if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, h->out, 0));   // results of slice i-2 have left the output buffers
         if ((rc = pairing_dev(c, (const uint64_t*)h->buf[0], (const uint64_t*)h->buf[1], inf1 ? (const uint8_t*)h->buf[2] : nullptr,
@@ -886,9 +708,7 @@ int host_sliced_impl(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const u
         if (i + 1 < nsl && (rc = upload(i + 1))) return rc;
         if (i >= 1 && (rc = download(i - 1))) return rc;
     }
-    if ((rc = down_job.finish(nullptr))) return rc;      // slice nsl-2's (download() below starts the last one)
     if ((rc = download(nsl - 1))) return rc;
-    if ((rc = down_job.finish(nullptr))) return rc;
     int flag = 1;
     HIPCHK(c, hipMemcpyAsync(&flag, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -913,7 +733,8 @@ int host_sliced(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_
 int stage_pairs(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf1, const uint8_t* inf2, size_t np, Staged* st) {
     int rc;
     if ((rc = ensure(c, 0, np * 96)) || (rc = ensure(c, 1, np * 192))) return rc;
-    if ((rc = upload_arrays(c, {{(char*)c->buf[0], (char*)g1, np * 96}, {(char*)c->buf[1], (char*)g2, np * 192}}, c->stream))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->buf[0], g1, np * 96, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->buf[1], g2, np * 192, hipMemcpyHostToDevice, c->stream));
     st->g1 = (const uint64_t*)c->buf[0];
     st->g2 = (const uint64_t*)c->buf[1];
     st->i1 = st->i2 = nullptr;
@@ -992,12 +813,6 @@ int zkp_init(int device, zkp_ctx** out_ctx) {
         c->host_slice = (size_t)atol(hsl);
         if (c->host_slice < 64) c->host_slice = 64;
     }
-    if (const char* sb = getenv("ZKP_HOST_STAGE_BYTES")) {
-        c->stage_bytes = (size_t)atol(sb);
-        if (c->stage_bytes < 256) c->stage_bytes = 256;
-        if (c->stage_bytes > ((size_t)64 << 20)) c->stage_bytes = (size_t)64 << 20;
-    }
-    if (const char* sg = getenv("ZKP_HOST_STAGE")) c->stage_threads = atoi(sg) != 0;
     const char* env = getenv("ZKP_KERNEL");
     if (env) {
         if (!strcmp(env, "thread")) c->kernel = ZKP_KERNEL_THREAD;
@@ -1025,15 +840,6 @@ void zkp_free(zkp_ctx* c) {
         if (c->hs[i].in) (void)hipEventDestroy(c->hs[i].in);
         if (c->hs[i].done) (void)hipEventDestroy(c->hs[i].done);
         if (c->hs[i].out) (void)hipEventDestroy(c->hs[i].out);
-    }
-    for (int i = 0; i < zkp_ctx::STAGE_LANES; i++) {
-        zkp_ctx::StageLane& L = c->lane[i];
-        for (int j = 0; j < 2; j++) {
-            if (L.pin[j]) (void)hipHostFree(L.pin[j]);
-            if (L.ev[j]) (void)hipEventDestroy(L.ev[j]);
-        }
-        if (L.fin) (void)hipEventDestroy(L.fin);
-        if (L.s) (void)hipStreamDestroy(L.s);
     }
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
@@ -1361,7 +1167,7 @@ int zkp_pairing_batch(zkp_ctx* c, const uint64_t* g1, const uint64_t* g2, const 
     Staged st;
     if ((rc = stage_pairs(c, g1, g2, inf1, inf2, n, &st)) || (rc = ensure(c, 4, n * 576))) return rc;
     if ((rc = pairing_dev(c, st.g1, st.g2, st.i1, st.i2, n, 1, (uint64_t*)c->buf[4], nullptr, nullptr, c->stream))) return rc;
-    if ((rc = download_array(c, out_gt, c->buf[4], n * 576, c->stream))) return rc;
+    HIPCHK(c, hipMemcpyAsync(out_gt, c->buf[4], n * 576, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ZKP_OK;
 }
@@ -1572,7 +1378,10 @@ int zkp_points_check_batch(zkp_ctx* c, const uint8_t* g1_bytes, const uint8_t* g
         return rc;
     uint8_t* d1 = (uint8_t*)c->pc[PC_BYTES];
     uint8_t* d2 = d1 + np * 96;
-    if (np && (rc = upload_arrays(c, {{(char*)d1, (char*)g1_bytes, np * 96}, {(char*)d2, (char*)g2_bytes, np * 192}}, c->stream))) return rc;
+    if (np) {
+        HIPCHK(c, hipMemcpyAsync(d1, g1_bytes, np * 96, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d2, g2_bytes, np * 192, hipMemcpyHostToDevice, c->stream));
+    }
     if ((rc = points_check_dev(c, d1, d2, n_checks, k, nullptr, nullptr, nullptr, c->d_flag + 1, c->stream))) return rc;
     if (st1 && np) HIPCHK(c, hipMemcpyAsync(st1, c->pc[PC_ST1], np, hipMemcpyDeviceToHost, c->stream));
     if (st2 && np) HIPCHK(c, hipMemcpyAsync(st2, c->pc[PC_ST2], np, hipMemcpyDeviceToHost, c->stream));
