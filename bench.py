@@ -643,7 +643,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import batch_sweep
             sizes = [x for x in batch_sweep.DEFAULT_SIZES if x <= n // 4 or x == 1]
-            rows = batch_sweep.sweep(eng, g1, g2, sizes, (1, 3))
+            rows = batch_sweep.sweep(eng, g1, g2, sizes, (1, 3), graph=True)
             full = {1: n / kern_ms}                              # checks per ms of the full pass (k = 1); k = 3: config 4's rate
             if secondary and secondary.get("config4_three_pair_checks"):
                 full[3] = secondary["config4_three_pair_checks"]["checks"] / secondary["config4_three_pair_checks"]["ms"]
@@ -655,7 +655,8 @@ def main():
             sweep = {"rows": rows, "full_rate_checks_per_s": {str(k_): v * 1e3 for k_, v in full.items()},
                      "what": "one zkp_pairing_gt_check_batch_dev call per row (Gt + ok bytes + flag out): ms_call_sync = call + stream synchronisation as a "
                              "host sees it (mean), ms_queued = calls queued back to back (HIP events), checks_per_s from the latter; "
-                             "frac_of_full_rate against the 2^20-pair pass (k = 1) / config 4 (k = 3) of this run.  A single pairing walks ~30 "
+                             "frac_of_full_rate against the 2^20-pair pass (k = 1) / config 4 (k = 3) of this run; hipgraph (n * k <= 4096) = the same call "
+                             "captured into a hipGraph and replayed, bytes compared with the plain call.  A single pairing walks ~30 "
                              "dependent launches of one wavefront each: launch gaps are 0.7 % of it (profiles/r06/v58_trace_n1.txt), the rest "
                              "is one wavefront's instruction chain - flat up to ~4096 checks, where the GPU starts to fill"}
             # a STREAM of medium batches (what a verifier with many config-2-sized jobs has): the same calls alternating over two / three

@@ -185,7 +185,8 @@ int zkp_tower_op_batch(zkp_ctx* ctx, int op, const uint64_t* a, const uint64_t* 
  * the internal pipeline streams join the capture through their fork / join events.  The hand-over of the context's workspace between
  * calls on DIFFERENT streams (an event per context) is skipped under capture: order a replayed graph against the context's other
  * calls yourself.  Measured (profiles/r06/v58_trace_n1.txt): launch gaps are 0.7 % of a single pairing's 3.8 ms - the kernels are
- * bound by one wavefront's dependent instruction chain - so a graph saves nothing here; capture is supported, not needed. */
+ * bound by one wavefront's dependent instruction chain - and a captured call replays in 3.50 ms against 3.54 ms plain (bench line,
+ * batch_sweep.rows[].hipgraph): capture is supported, the library itself keeps no graph cache. */
 int zkp_pairing_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1, const void* d_inf2,
                           size_t n, void* d_out_gt, void* stream);
 int zkp_multi_miller_loop_batch_dev(zkp_ctx* ctx, const void* d_g1, const void* d_g2, const void* d_inf1,

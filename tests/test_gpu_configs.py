@@ -534,6 +534,36 @@ def test_points_check_is_asynchronous_and_capturable(eng):
     assert not st1.any() and int(flag.item()) == 0
 
 
+def test_pairing_call_captured_into_a_hipgraph_equals_the_plain_call(eng):
+    """the launch sequence of a small batch captured into a hipGraph and replayed gives the plain path's bytes at
+    n = 1, 5, 320, 4096 (k = 1) and n = 1, 320 (k = 3).  (Whether replaying it is FASTER is bench.py's business - batch_sweep.rows[].hipgraph:
+    launch gaps are 0.7 % of a single pairing, profiles/r06/v62_trace_n1.txt.)"""
+    import torch
+    from zkvm_pairings_amd import synthetic
+    dev = torch.device("cuda", 0)
+    g1, g2, _, _ = synthetic.random_pairs(eng, 4096, seed=4242, device_tensors=True)
+    for k, sizes in ((1, (1, 5, 320, 4096)), (3, (1, 320))):
+        for n in sizes:
+            a, b = g1[: n * k], g2[: n * k]
+            gt = torch.empty((n, 72), dtype=torch.int64, device=dev)
+            ok = torch.empty(n, dtype=torch.uint8, device=dev)
+            flag = torch.empty(1, dtype=torch.int32, device=dev)
+            eng.pairing_gt_check(a, b, k, gt, ok, flag)
+            torch.cuda.synchronize()
+            want = (gt.clone(), ok.clone(), flag.clone())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eng.pairing_gt_check(a, b, k, gt, ok, flag)
+            gt.zero_(), ok.fill_(9), flag.fill_(7)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(gt, want[0]) and torch.equal(ok, want[1]) and torch.equal(flag, want[2]), (k, n)
+            if n == 1 and k == 1:
+                got = gt.cpu().numpy().view(np.uint64)
+                assert np.array_equal(got, o.pairing_batch(a.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64), nthreads=1))
+            del graph
+
+
 def test_checks_with_more_than_eight_pairs_share_their_squarings():
     """round 5: a check of 9..16 pairs runs through ONE accumulator (the run-time-k Miller program), more pairs in groups of 16.  The Miller
     values equal those of the rounds-1-4 flow (groups of eight joined by f12mul: ZKP_COOP_NO_STREAM=1) for k = 8 .. 96 - and for groups of
