@@ -498,6 +498,62 @@ def test_points_check_skips_the_pairing_of_invalid_checks(eng):
         eng.set_kernel("auto")
 
 
+def test_points_check_device_count_across_chunks_groups_and_super_chunks(monkeypatch):
+    """the device-resident count (NDev) with every offset the plans produce: small chunks over three pipelines, two super-chunks, phase C
+    in parts, and checks of 1, 2, 9 and 20 pairs (unrolled program, run-time-k program, groups joined by f12mul) - a scattered third of
+    the checks carries an invalid point, the rest cancel to the identity; status bytes, ok bytes and the flag equal the expectation by
+    construction, and an all-invalid and an all-valid batch behave"""
+    import torch
+    from zkvm_pairings_amd import PairingEngine, configs, synthetic
+    monkeypatch.setenv("ZKP_COOP_CHUNK", "320")
+    monkeypatch.setenv("ZKP_COOP_STREAMS", "3")
+    monkeypatch.setenv("ZKP_COOP_SUPER", "640")
+    monkeypatch.setenv("ZKP_COOP_C_SPLIT", "2")
+    monkeypatch.setenv("ZKP_COOP_MAX_STREAM", "16")
+    e = PairingEngine(0)
+    dev = torch.device("cuda", 0)
+    try:
+        rng = np.random.default_rng(66)
+        for k, n in ((1, 1003), (2, 1003), (9, 700), (20, 333)):
+            h = (k + 1) // 2                                           # pairs (P, Q), (-P, Q), ... : an even k cancels; odd k: the last pair has P = infinity
+            g1, g2, _, _ = synthetic.random_pairs(e, n * h, seed=1000 + k)
+            neg = configs.negate_g1(e, g1)
+            P = np.stack([g1, neg], axis=1).reshape(n, 2 * h, 12)[:, :k].reshape(n * k, 12)
+            Q = np.repeat(g2, 2, axis=0).reshape(n, 2 * h, 24)[:, :k].reshape(n * k, 24)
+            b1 = np.frombuffer(e.encode_points(P, 1), dtype=np.uint8).reshape(n * k, 96).copy()
+            b2 = np.frombuffer(e.encode_points(Q, 2), dtype=np.uint8).reshape(n * k, 192).copy()
+            if k % 2:                                                  # the unpaired last point of a check: the infinity encoding
+                b1[k - 1::k] = 0
+                b1[k - 1::k, 0] = 0x40
+            bad_checks = rng.random(n) < 0.33
+            bad_checks[[0, n - 1]] = [True, False]
+            which = rng.integers(0, k, n)
+            idx = np.flatnonzero(bad_checks) * k + which[bad_checks]
+            b1[idx, 95] ^= 1                                           # off the curve (an infinity encoding becomes malformed: status 2)
+            t1, t2 = torch.from_numpy(b1).to(dev), torch.from_numpy(b2).to(dev)
+            st1 = torch.empty(n * k, dtype=torch.uint8, device=dev)
+            st2 = torch.empty_like(st1)
+            ok = torch.empty(n, dtype=torch.uint8, device=dev)
+            flag = torch.empty(1, dtype=torch.int32, device=dev)
+            e.points_check(t1, t2, k, st1, st2, ok, flag)
+            torch.cuda.synchronize()
+            s1 = st1.cpu().numpy()
+            assert (s1[idx] != 0).all() and int((s1 != 0).sum()) == len(idx) and not st2.any(), k
+            assert np.array_equal(ok.cpu().numpy(), (~bad_checks).astype(np.uint8)) and int(flag.item()) == 0, k
+            hs1, hs2, hok, hall = e.points_check(b1, b2, k)            # the host flavour: the same bytes
+            assert np.array_equal(hs1, s1) and np.array_equal(hok, ok.cpu().numpy()) and not hall
+            good = np.flatnonzero(~bad_checks)
+            sel = (good[:, None] * k + np.arange(k)[None, :]).reshape(-1)
+            _, _, okg, allg = e.points_check(b1[sel], b2[sel], k)      # every check valid: the count equals the batch
+            assert okg.all() and allg, k
+            badc = np.flatnonzero(bad_checks)
+            sel = (badc[:, None] * k + np.arange(k)[None, :]).reshape(-1)
+            _, _, okb, allb = e.points_check(b1[sel], b2[sel], k)      # no check valid: the count is zero, every pairing launch is empty
+            assert not okb.any() and not allb, k
+    finally:
+        e.close()
+
+
 def test_points_check_is_asynchronous_and_capturable(eng):
     """round 6: zkp_points_check_batch_dev no longer reads anything back - the call can be captured into a hipGraph
     (a host synchronisation or an allocation inside the capture would fail it) and the replayed graph gives the bytes of the plain call,
