@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6, second GPU call: the stagger knobs (ZKP_COOP_STAGGER, ZKP_COOP_C_SPLIT_MIN, ZKP_COOP_SPLIT_MIN) over shard sizes
+# NOTE: ZKP_COOP_STAGGER existed only in the experiment build of this sweep (removed: profiles/r06/knob_sweeps.txt r6b)
 set -o pipefail
 out=gpurun_out/r6b; mkdir -p $out
 sizes=16384,32768,65536,131072,262144,524288,1048576
