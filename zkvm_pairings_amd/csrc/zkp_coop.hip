@@ -1796,9 +1796,19 @@ constexpr int N = 13;
 constexpr int32_t M30 = 0x3fffffff;
 __device__ __constant__ const int32_t PL[N] = {ZKP30_P_LIMBS};
 
+// Round 6: the transition matrix is tracked in PACKED 16-bit halves - (u, v) in one register, (q, r) in another - over three runs of ten steps
+// (entries <= 2^10), and the three 2 x 2 matrices are multiplied together afterwards (24-bit multiplies; the products wrap mod 2^32 and
+// the true entries are <= 2^30).  A conditional negation / masked addition / doubling of BOTH entries of a row is one v_pk_* instruction:
+// 19 instead of 24 instructions per step.  The same matrix as the plain 30-step loop (ZKP_SG_PLAIN_DIVSTEPS=1 builds that one: the A/B
+// baseline), hence the same inverse: tests/test_gpu_parity.py::test_divstep_inversion_equals_fermat.
+#ifndef ZKP_SG_PLAIN_DIVSTEPS
+#define ZKP_SG_PLAIN_DIVSTEPS 0
+#endif
+typedef short zkp_s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void divsteps30(int32_t& eta, uint32_t f, uint32_t g, int32_t& u_, int32_t& v_, int32_t& q_, int32_t& r_) {
+#if ZKP_SG_PLAIN_DIVSTEPS
     uint32_t u = 1, v = 0, q = 0, r = 1, e = (uint32_t)eta;
-#pragma unroll 6      // round 6: five trips instead of thirty - a taken branch costs a lone wavefront about three of the step's 24 instructions
+#pragma unroll 6      // five trips instead of thirty - a taken branch costs a lone wavefront about three of the step's 24 instructions
     for (int i = 0; i < 30; i++) {
         uint32_t c1 = (uint32_t)((int32_t)e >> 31);          // eta < 0  <=>  delta > 0
         const uint32_t c2 = 0u - (g & 1u);
@@ -1810,6 +1820,39 @@ __device__ __forceinline__ void divsteps30(int32_t& eta, uint32_t f, uint32_t g,
         g >>= 1; u <<= 1; v <<= 1;
     }
     eta = (int32_t)e; u_ = (int32_t)u; v_ = (int32_t)v; q_ = (int32_t)q; r_ = (int32_t)r;
+#else
+    uint32_t e = (uint32_t)eta;
+    int32_t U = 1, V = 0, Q = 0, R = 1;                        // the product of the runs so far
+#pragma unroll
+    for (int run = 0; run < 3; run++) {
+        zkp_s2 P = {1, 0}, T = {0, 1};                         // rows (u, v) and (q, r) of this run's matrix
+#pragma unroll 5
+        for (int i = 0; i < 10; i++) {
+            uint32_t c1 = (uint32_t)((int32_t)e >> 31);        // eta < 0  <=>  delta > 0
+            const uint32_t c2 = 0u - (g & 1u);
+            const uint32_t x = (f ^ c1) - c1;
+            const zkp_s2 m1 = __builtin_bit_cast(zkp_s2, c1), m2 = __builtin_bit_cast(zkp_s2, c2);
+            const zkp_s2 Y = (P ^ m1) - m1;                    // (-u, -v) where delta > 0
+            g += x & c2;
+            T += Y & m2;
+            c1 &= c2;                                          // delta > 0 and g odd: swap roles
+            e = (e ^ c1) - (c1 + 1u);
+            f += g & c1;
+            P += T & __builtin_bit_cast(zkp_s2, c1);
+            g >>= 1;
+            P += P;                                            // (u, v) <<= 1
+        }
+        const int32_t u2 = P.x, v2 = P.y, q2 = T.x, r2 = T.y;
+        if (run == 0) {
+            U = u2; V = v2; Q = q2; R = r2;
+        } else {                                               // M <- M_run * M: entries of M_run <= 2^10, of M <= 2^20: 24-bit operands
+            const int32_t nU = __mul24(u2, U) + __mul24(v2, Q), nV = __mul24(u2, V) + __mul24(v2, R);
+            const int32_t nQ = __mul24(q2, U) + __mul24(r2, Q), nR = __mul24(q2, V) + __mul24(r2, R);
+            U = nU; V = nV; Q = nQ; R = nR;
+        }
+    }
+    eta = (int32_t)e; u_ = U; v_ = V; q_ = Q; r_ = R;
+#endif
 }
 // Round 6: the limbs and matrix entries are pinned to 32-bit registers (an empty asm the optimiser cannot see through).  Without it
 // LLVM carries a limb as the masked 64-bit carry word it came from and expands every (int64) u * limb into the 64 x 64-bit pattern
