@@ -817,6 +817,32 @@ def test_chunk_and_group_boundaries(monkeypatch):
         e.close()
 
 
+def test_primer_launches_change_no_byte(monkeypatch):
+    """round 6: small grids in the dispatcher's bad bands are preceded by an empty kernel on the same grid (zkp_coop.hip prime(): placement,
+    not arithmetic).  ZKP_COOP_PRIME=2 primes EVERY grid of 1 .. 12 workgroups per compute unit, 0 none: the same Gt, ok bytes and flag as the
+    default on batch sizes whose launches fall into the bands (1,024 / 2,048 k_ksq wavefronts, 768 k_prep_lines wavefronts), k = 1 and 3"""
+    from zkvm_pairings_amd import PairingEngine, synthetic
+    res = {}
+    for mode in ("1", "0", "2"):
+        monkeypatch.setenv("ZKP_COOP_PRIME", mode)
+        e = PairingEngine(0)
+        try:
+            if not res:
+                g1, g2, _, _ = synthetic.random_pairs(e, 32768, seed=909)
+            out = []
+            for n, k in ((16384, 1), (24576, 1), (32768, 1), (5461, 3)):
+                gt = e.pairing(g1[:n], g2[:n]) if k == 1 else None
+                ok, allok = e.pairing_check(g1[: n * k], g2[: n * k], k)
+                out.append((gt, ok, allok))
+            res[mode] = out
+        finally:
+            e.close()
+    for mode in ("0", "2"):
+        for (a_gt, a_ok, a_fl), (b_gt, b_ok, b_fl) in zip(res["1"], res[mode]):
+            assert (a_gt is None or np.array_equal(a_gt, b_gt)) and np.array_equal(a_ok, b_ok) and a_fl == b_fl, mode
+    assert np.array_equal(res["1"][0][0][:32], o.pairing_batch(g1[:32], g2[:32], nthreads=NTHREADS))
+
+
 def test_phase_c_in_parts_gives_the_same_gt(eng):
     """ZKP_COOP_C_SPLIT (phase C of a super-chunk in parts on the pipelines' streams - an experiment knob, off by default): the same
     Gt and flags as the single launch sequence, on a ragged batch that spans several chunks"""

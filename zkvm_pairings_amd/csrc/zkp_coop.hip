@@ -2281,6 +2281,18 @@ __global__ void k_fp28_op(int op, const uint64_t* a, const uint64_t* b, size_t n
     fp28_to_wire(out + 6 * i, r);
 }
 
+// the primer of prime(): a grid of one-wavefront workgroups that leave at once
+__global__ void __launch_bounds__(64) k_primer() {}
+
+// measurement only (ZKP_TIME_FILL=256): pseudo-random balanced 28-bit limbs as the timing hook's synthetic state - what real operands look like
+__global__ void k_fill_rand(int32_t* p, size_t n_words) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    uint64_t x = (i + 1) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    p[i] = (int32_t)((uint32_t)x >> 4) - (1 << 27);
+}
+
 }  // namespace
 
 // =============================================================================== host side
@@ -2305,6 +2317,10 @@ struct CoopDev {
     CoopPipe pipe[MAX_PIPES];
     plan::Knobs kn;          // chunking / splitting knobs, clamped (zkp_plan.hpp: the arithmetic the CPU test walks under sanitizers)
     bool inv_fermat;         // a^(p-2) instead of the division-step inversion (cross-check)
+    int cus;                 // compute units of the device
+    int prime_mask;          // ZKP_COOP_PRIME_MASK (experiments): which kernel classes are primed
+    bool prime_now;          // set per super-chunk by two_phase: batches of at most one chunk only (a larger one keeps the GPU full: nothing to place)
+    int prime;               // ZKP_COOP_PRIME: small grids in the dispatcher's bad bands are preceded by an empty grid of the same size (prime())
     int4* big_state;         // per-check state of a whole super-chunk (7.9 KB per check)
     size_t big_state_bytes;
     int4* vscratch;          // k_g2_valid_fast3: Montgomery limbs of the affine points (2 values x 4 quads per lane)
@@ -2317,6 +2333,7 @@ struct CoopDev {
     const uint32_t* n_dev;         // for the duration of one coop_pairing call: the device-resident check count (or null)
 };
 
+enum { PRIME_COOP = 1, PRIME_PREP = 2, PRIME_KSQ = 4, PRIME_INV = 8, PRIME_KDEC = 16 };      // kernel classes of prime()
 // kernel classes of coop_profile_pairing (include/zkp_pairings.h ZKP_PROFILE_*)
 enum { PROF_PREP = 0, PROF_MILLER, PROF_FEXP_A, PROF_INV, PROF_KSQ, PROF_KDEC_A, PROF_KDEC_B, PROF_C_DEEP, PROF_C_PLAIN, PROF_CLASSES };
 struct ProfScope {
@@ -2427,6 +2444,9 @@ hipError_t coop_init(CoopState* st, const hipDeviceProp_t& prop) {
     kn.c_single_min = (size_t)env_l("ZKP_COOP_C_SINGLE_MIN", (long)kn.chunk);
     d->kn = kn;
     d->inv_fermat = env_l("ZKP_COOP_INV_FERMAT", 0) != 0;
+    d->cus = prop.multiProcessorCount;
+    d->prime = (int)env_l("ZKP_COOP_PRIME", 1);
+    d->prime_mask = (int)env_l("ZKP_COOP_PRIME_MASK", PRIME_PREP | PRIME_KSQ | PRIME_INV);
     for (int i = 0; i < MAX_PIPES; i++) d->pipe[i].owner = d;
     for (int i = 0; i < d->kn.n_pipes; i++) {
         if ((e = hipStreamCreateWithFlags(&d->pipe[i].stream, hipStreamNonBlocking)) != hipSuccess) return e;
@@ -2471,6 +2491,27 @@ static hipError_t ensure_buf(int4** p, size_t* cap, size_t bytes) {
     return e;
 }
 
+// Round 6: where the wavefronts of a SMALL grid land depends on what the dispatcher placed last.  On an idle GPU, or behind a kernel of
+// another shape, 1,024 one-wavefront workgroups (one per SIMD if spread evenly) come to lie two to a SIMD on half of the SIMDs and take as
+// long as 1,536 (k_ksq: 375 us where 768 wavefronts take 220); 2,048 come to lie three to a SIMD (550 us where 1,536 take 385).  Behind a
+// grid of the SAME size they spread evenly - even when that grid is an empty kernel (tools/occupancy_probe.py, profiles/r06/placement_probe.txt).
+// So a launch whose grid falls into a bad band is preceded by a PRIMER: an empty kernel on the same grid (3-4 us).  The bands, measured per
+// kernel class (profiles/r06/knob_sweeps.txt r6o, r6p): k_ksq more than 3 and at most 4, or more than 6 and at most 8 workgroups per compute
+// unit (16,384 / 32,768 checks: 6.5 -> 5.8 / 10.4 -> 9.6 ms per pass); k_prep_lines and k_batch_inv more than 2 and at most 3 (20,480 /
+// 24,576 pairs: 7.5 -> 6.8 / 8.3 -> 7.5 ms); the interpreter's and the decompression's launches gain nothing and are not primed.  Only
+// batches of at most one chunk are primed (a larger one keeps the GPU full).  LDS padding to cap the workgroups per
+// compute unit does nothing here (the imbalance is between the SIMDs of a compute unit).  ZKP_COOP_PRIME: 0 off, 1 the bands (default),
+// 2 every grid of 1 .. 12 workgroups per compute unit; ZKP_COOP_PRIME_MASK: the kernel classes (A/B).
+static hipError_t prime(const CoopDev* d, hipStream_t s, size_t blocks, int cls) {
+    if (!d || !d->prime || d->cus <= 0 || !blocks || !(d->prime_mask & cls) || !d->prime_now) return hipSuccess;
+    const size_t c = (size_t)d->cus;
+    const bool band = cls == PRIME_KSQ ? (blocks > 3 * c && blocks <= 4 * c) || (blocks > 6 * c && blocks <= 8 * c)      // three wavefronts per SIMD
+                                       : (blocks > 2 * c && blocks <= 3 * c);
+    if (!(band || (d->prime >= 2 && blocks > c && blocks <= 12 * c))) return hipSuccess;
+    hipLaunchKernelGGL(k_primer, dim3((unsigned)blocks), dim3(64), 0, s);
+    return hipGetLastError();
+}
+
 static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks, uint32_t nc, uint32_t k, const uint64_t* wire_in,
                            uint64_t* wire_out, uint8_t* ok, int* all_ok, uint32_t st_off = 0, uint32_t chk_off = 0) {
     hipStream_t s = pp->stream;
@@ -2506,6 +2547,7 @@ static hipError_t run_prog(CoopDev* d, CoopPipe* pp, int prog, uint32_t n_checks
     static const long lds_pad = getenv("ZKP_COOP_LDS_PAD") ? atol(getenv("ZKP_COOP_LDS_PAD")) : 0;
     if (lds_pad > 0) lds_bytes += (size_t)lds_pad;
     unsigned blocks = (n_checks + GROUPS - 1) / GROUPS;
+    { hipError_t ep = prime(d, s, blocks, PRIME_COOP); if (ep != hipSuccess) return ep; }
     ProfScope prof(d, s, cfg == 1 ? PROF_MILLER : cfg == 2 ? PROF_C_DEEP : d->prof_phase_c ? PROF_C_PLAIN : PROF_FEXP_A);
     if (cfg == 2)
         hipLaunchKernelGGL((k_coop<ZKP_COOP_DEEP_NSLOT, ZKP_COOP_DEEP_NCONST>), dim3(blocks), dim3(64 * WGW), lds_bytes, s, a);
@@ -2546,13 +2588,15 @@ static hipError_t prep(CoopPipe* pp, const uint64_t* g1, const uint64_t* g2, con
     hipStream_t s = pp->stream;
     size_t p0 = base_check * k_in;
     uint32_t n_pairs = n * g;
+    const size_t prep_lds = 4 * 4 * 64 * sizeof(int4);
+    { hipError_t ep = prime(pp->owner, s, (2 * (size_t)n_pairs + 63) / 64, PRIME_PREP); if (ep != hipSuccess) return ep; }
     ProfScope prof(pp->owner, s, PROF_PREP);
     static const bool no_cln = getenv("ZKP_PREP_NO_CLN") && atoi(getenv("ZKP_PREP_NO_CLN"));   // A/B knob (value cached, not the pointer)
     if (fused && !no_cln)
-        hipLaunchKernelGGL(k_prep_lines<true>, dim3((2 * n_pairs + 63) / 64), dim3(64), 4 * 4 * 64 * sizeof(int4), s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
+        hipLaunchKernelGGL(k_prep_lines<true>, dim3((2 * n_pairs + 63) / 64), dim3(64), prep_lds, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
                            i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines, pp->nd);
     else
-        hipLaunchKernelGGL(k_prep_lines<false>, dim3((2 * n_pairs + 63) / 64), dim3(64), 4 * 4 * 64 * sizeof(int4), s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
+        hipLaunchKernelGGL(k_prep_lines<false>, dim3((2 * n_pairs + 63) / 64), dim3(64), prep_lds, s, g1 + 12 * p0, g2 + 24 * p0, i1 ? i1 + p0 : nullptr,
                            i2 ? i2 + p0 : nullptr, n_pairs, g, k_in, j0, n, pp->lines, pp->nd);
     return hipGetLastError();
 }
@@ -2623,6 +2667,7 @@ hipError_t coop_miller(CoopState* st, const uint64_t* g1, const uint64_t* g2, co
                        uint64_t* out, hipStream_t s) {
     CoopDev* d = (CoopDev*)st->d_prog;
     if (!coop_supports_k(k)) return hipErrorNotSupported;
+    d->prime_now = n_checks <= d->kn.chunk;
     return for_chunks(d, n_checks, k, true, true, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
         return miller_on_pipe(d, pp, g1, g2, i1, i2, base, n, n, k, out + 72 * base);
     });
@@ -2634,6 +2679,7 @@ static hipError_t run_ksq(hipStream_t s, int4* state, uint32_t n_checks, uint32_
                           uint64_t snap_mask, CoopDev* d = nullptr, NDev nd = NDev{nullptr, 0}) {
     if (!n_checks || !nsq) return hipSuccess;
     if (snap_mask && nsq > 64) return hipErrorInvalidValue;   // snapshot bits exist for the first 64 squarings only
+    { hipError_t ep = prime(d, s, (n_checks + KS_CHECKS - 1) / KS_CHECKS, PRIME_KSQ); if (ep != hipSuccess) return ep; }
     ProfScope prof(d, s, PROF_KSQ);
     hipLaunchKernelGGL(k_ksq, dim3((n_checks + KS_CHECKS - 1) / KS_CHECKS), dim3(64), 7 * 64 * sizeof(int4), s, state, n_checks, nc, elem_in, elem_snap, nsq, snap_mask, nd);
     return hipGetLastError();
@@ -2648,6 +2694,7 @@ static hipError_t run_inv(CoopDev* d, hipStream_t s, int4* state, uint32_t n, ui
     const plan::Inv pi = plan::plan_inv(d->kn, n, count);
     const uint32_t B = pi.batch;
     const size_t lanes = pi.lanes;
+    { hipError_t ep = prime(d, s, (lanes + 63) / 64, PRIME_INV); if (ep != hipSuccess) return ep; }
     ProfScope prof(d, s, PROF_INV);
     hipLaunchKernelGGL(k_batch_inv, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, state, n, nc, B | (d->inv_fermat ? 0x80000000u : 0u), elem_n,
                        elem_ninv, count, nd);
@@ -2670,7 +2717,8 @@ static hipError_t run_fexp_c(CoopDev* d, CoopPipe* pp, uint32_t n, uint32_t nc, 
                 e = run_ksq(pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, ps.mask, d, pp->nd);
                 break;
             case ZKP_PLAN_KDEC_A: {
-                ProfScope prof(d, pp->stream, PROF_KDEC_A);
+                { hipError_t ep = prime(d, pp->stream, (2 * (size_t)n * ps.b + 63) / 64, PRIME_KDEC); if (ep != hipSuccess) return ep; }
+            ProfScope prof(d, pp->stream, PROF_KDEC_A);
                 hipLaunchKernelGGL(k_kdec_a, dim3((unsigned)((2 * (size_t)n * ps.b + 63) / 64)), dim3(64), 0, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, pp->nd);
                 e = hipGetLastError();
                 break;
@@ -2679,7 +2727,8 @@ static hipError_t run_fexp_c(CoopDev* d, CoopPipe* pp, uint32_t n, uint32_t nc, 
                 e = run_inv(d, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, pp->nd);
                 break;
             case ZKP_PLAN_KDEC_B: {
-                ProfScope prof(d, pp->stream, PROF_KDEC_B);
+                { hipError_t ep = prime(d, pp->stream, (2 * (size_t)n * ps.b + 63) / 64, PRIME_KDEC); if (ep != hipSuccess) return ep; }
+            ProfScope prof(d, pp->stream, PROF_KDEC_B);
                 hipLaunchKernelGGL(k_kdec_b, dim3((unsigned)((2 * (size_t)n * ps.b + 63) / 64)), dim3(64), 0, pp->stream, pp->state, n, nc, ps.a, ps.b, ps.c, pp->nd);
                 e = hipGetLastError();
                 break;
@@ -2703,6 +2752,7 @@ static hipError_t two_phase(CoopDev* d, size_t n_total, size_t k, bool need_line
     hipError_t e;
     for (size_t sb = 0; sb < n_total; sb += d->kn.super) {
         const size_t ns = n_total - sb < d->kn.super ? n_total - sb : d->kn.super;
+        d->prime_now = ns <= d->kn.chunk && n_total <= d->kn.chunk;
         if ((e = ensure_buf(&d->big_state, &d->big_state_bytes, plan::state_bytes(ns))) != hipSuccess) return e;
         e = for_chunks(d, ns, k, need_lines, false, s, [&](CoopPipe* pp, size_t base, uint32_t n) -> hipError_t {
             CoopPipe v = *pp;
@@ -2821,6 +2871,7 @@ hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, ui
                                   ZKP_PROG_TW_FP12_MUL, ZKP_PROG_TW_FP12_SQR, ZKP_PROG_TW_FP12_014, ZKP_PROG_TW_FP12_FROB, ZKP_PROG_TW_FP12_CONJ,
                                   ZKP_PROG_TW_CYC_SQR};
     if (op < 0 || op > 20 || n > 0x3fffffffu) return hipErrorInvalidValue;
+    d->prime_now = n <= d->kn.chunk;
     hipError_t e;
     for (size_t base = 0; base < n; base += d->kn.chunk) {
         const uint32_t m = (uint32_t)(n - base < d->kn.chunk ? n - base : d->kn.chunk);
@@ -2867,7 +2918,7 @@ hipError_t coop_tower_op(CoopState* st, int op, const uint64_t* ab, size_t n, ui
             if ((e = run_prog(d, &v, ZKP_PROG_TW_TO_SNAP, m, m, 1, ab + 72 * base, nullptr, nullptr, nullptr)) != hipSuccess) return e;
         } else {
             if ((e = run_prog(d, &v, ZKP_PROG_TW_TO_STATE, m, m, 1, ab + 72 * base, nullptr, nullptr, nullptr)) != hipSuccess) return e;
-            if ((e = run_ksq(s, v.state, m, m, 0, ZKP_COOP_ST_SNAP, repeat, 1ull << (repeat - 1))) != hipSuccess) return e;
+            if ((e = run_ksq(s, v.state, m, m, 0, ZKP_COOP_ST_SNAP, repeat, 1ull << (repeat - 1), d)) != hipSuccess) return e;
         }
         hipLaunchKernelGGL(k_kdec_a, dim3((2 * m + 63) / 64), dim3(64), 0, s, v.state, m, m, (uint32_t)ZKP_COOP_ST_SNAP, 1u, (uint32_t)ZKP_COOP_ST_KN, NDev{nullptr, 0});
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -2888,14 +2939,31 @@ hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, hip
     static const int ids[9] = {ZKP_PROG_TIME_T1, ZKP_PROG_TIME_T3, ZKP_PROG_TIME_T3E, ZKP_PROG_TIME_T6, ZKP_PROG_TIME_T12, ZKP_PROG_TIME_LIN,
                                ZKP_PROG_TIME_CYC, ZKP_PROG_TIME_CYCSD, ZKP_PROG_TIME_FILL};
     static const int ids2[3] = {ZKP_PROG_TIME_T6S, ZKP_PROG_TIME_T12S, ZKP_PROG_TIME_T12B};   // which 12..14: one-slot / B-two-slot operand forms
-    if (which < 0 || which > 15 || !n || n > 0x7fffffffu || ((which == 10 || which == 11 || which == 15) && n > d->kn.chunk)) return hipErrorInvalidValue;
+    if (which < 0 || which > 19 || !n || n > 0x7fffffffu || ((which == 10 || which == 11 || which == 15) && n > d->kn.chunk)) return hipErrorInvalidValue;
     hipError_t e = ensure_buf(&d->pipe[0].state, &d->pipe[0].state_bytes, (size_t)ST_SIZE * n * 64);
     if (e != hipSuccess) return e;
     if ((which == 10 || which == 11 || which == 15) && (e = ensure_buf(&d->pipe[0].lines, &d->pipe[0].lines_bytes, (size_t)NLINES * 6 * n * 64)) != hipSuccess) return e;
     CoopPipe v = d->pipe[0];
     v.stream = s;
+    bool timed = false;      // which 16 / 17: 57 squarings (one run of the pass) behind ANOTHER kernel (a step program) / behind an idle GPU
     auto once = [&]() -> hipError_t {
         if (which == 9) return run_ksq(s, v.state, (uint32_t)n, (uint32_t)n, 0, 12, 400, 0);   // timing run: no snapshots (a mask needs nsq <= 64)
+        if (which >= 16 && which <= 19) {      // 18: behind a ONE-squaring launch of the same grid; 19: behind a step program and that
+            if (!timed) {
+                timed = true;
+                if (which == 17) return hipStreamSynchronize(s);
+                static const bool empty_primer = getenv("ZKP_PRIMER_EMPTY") && atoi(getenv("ZKP_PRIMER_EMPTY")) != 0;
+                if (which == 18 && empty_primer) {
+                    hipLaunchKernelGGL(k_primer, dim3((unsigned)((n + KS_CHECKS - 1) / KS_CHECKS)), dim3(64), 0, s);
+                    return hipGetLastError();
+                }
+                if (which == 18) return run_ksq(s, v.state, (uint32_t)n, (uint32_t)n, 0, 12, 1, 0);
+                hipError_t e1 = run_prog(d, &v, ZKP_PROG_TIME_T1, (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
+                if (e1 != hipSuccess || which == 16) return e1;
+                return run_ksq(s, v.state, (uint32_t)n, (uint32_t)n, 0, 12, 1, 0);
+            }
+            return run_ksq(s, v.state, (uint32_t)n, (uint32_t)n, 0, 12, 57, 0);
+        }
         if (which >= 12 && which <= 14) return run_prog(d, &v, ids2[which - 12], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
         if (which == 10 || which == 15) {                          // 15: the upstream-shaped lines (k_prep_lines<false>)
             const uint64_t* zero = (const uint64_t*)v.state;      // 36 u64 of zeros per pair: the state buffer is far larger
@@ -2904,7 +2972,15 @@ hipError_t coop_time_prog(CoopState* st, int which, size_t n, hipStream_t s, hip
         if (which == 11) return run_prog(d, &v, ZKP_PROG_MILLER1_STATE, (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
         return run_prog(d, &v, ids[which], (uint32_t)n, (uint32_t)n, 1, nullptr, nullptr, nullptr, nullptr);
     };
-    if (which != 11 && (e = hipMemsetAsync(v.state, 0, (size_t)ST_SIZE * n * 64, s)) != hipSuccess) return e;
+    // ZKP_TIME_FILL=<byte> (measurement only): the synthetic inputs are this byte repeated instead of zeros - the clock a kernel gets depends
+    // on the operand data (DESIGN_HISTORY section 4, round 5), so zeros flatter a multiply-add-dense kernel
+    static const int fill = getenv("ZKP_TIME_FILL") ? atoi(getenv("ZKP_TIME_FILL")) : 0;
+    if (which != 11 && fill < 256 && (e = hipMemsetAsync(v.state, fill & 0xff, (size_t)ST_SIZE * n * 64, s)) != hipSuccess) return e;
+    if (which != 11 && fill >= 256) {
+        const size_t words = (size_t)ST_SIZE * n * 16;
+        hipLaunchKernelGGL(k_fill_rand, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (int32_t*)v.state, words);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if ((e = once()) != hipSuccess) return e;
     if ((e = hipEventRecord(e0, s)) != hipSuccess) return e;
     if ((e = once()) != hipSuccess) return e;
